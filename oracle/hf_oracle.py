@@ -1,0 +1,227 @@
+"""ctypes binding of the CPU oracle (oracle/hf_oracle.c).
+
+TEST INFRASTRUCTURE ONLY -- see the header of oracle/hf_oracle.h.  Importers:
+tests/, __graft_entry__.smoke(), bench.py's cpu_baseline leg.  The product
+package never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libhf_oracle.so")
+
+RAY_MINIMAL, RAY_UV, RAY_DPDUV, RAY_SHADINGFRAME = 0x1, 0x2, 0x4, 0x8
+RAY_BOUNDARYTEST, RAY_FOLLOWSHAPE, RAY_DETACHSHAPE = 0x40, 0x80, 0x100
+RAY_ALL = RAY_UV | RAY_DPDUV | RAY_SHADINGFRAME
+
+SI_FIELDS = [("t", 1), ("p", 3), ("n", 3), ("uv", 2), ("sh_n", 3), ("dp_du", 3),
+             ("dp_dv", 3), ("boundary_test", 1), ("sh_s", 3), ("sh_t", 3), ("wi", 3)]
+GRAD_FIELDS = [("t", 1), ("p", 3), ("n", 3), ("uv", 2), ("sh_n", 3), ("dp_du", 3), ("dp_dv", 3)]
+
+
+def build(force=False):
+    """Compile libhf_oracle.so with the committed Makefile."""
+    src = os.path.join(_HERE, "hf_oracle.c")
+    if (force or not os.path.exists(_LIB_PATH)
+            or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src)):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libhf_oracle.so"],
+                              stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+_fp = C.POINTER(C.c_float)
+_u8p = C.POINTER(C.c_uint8)
+_u32p = C.POINTER(C.c_uint32)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        L.hfo_create.restype = C.c_void_p
+        L.hfo_create.argtypes = [C.c_int, C.c_int, _fp, C.c_float, _fp, _fp, C.c_int]
+        L.hfo_destroy.argtypes = [C.c_void_p]
+        L.hfo_set_heights.argtypes = [C.c_void_p, _fp]
+        L.hfo_num_levels.argtypes = [C.c_void_p]
+        L.hfo_get_mip.argtypes = [C.c_void_p, C.c_int, _fp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.hfo_bbox.argtypes = [C.c_void_p, _fp]
+        L.hfo_vertex.argtypes = [C.c_void_p, C.c_int, C.c_int, _fp]
+        L.hfo_intersect_batch.argtypes = [C.c_void_p, C.c_int64, C.POINTER(_fp), _u8p, C.c_int,
+                                          C.c_int, _fp, _fp, _fp, _u32p]
+        L.hfo_ray_test_batch.argtypes = [C.c_void_p, C.c_int64, C.POINTER(_fp), _u8p, C.c_int,
+                                         C.c_int, _u8p]
+        L.hfo_compute_si_batch.restype = C.c_int
+        L.hfo_compute_si_batch.argtypes = [C.c_void_p, C.c_int64, C.POINTER(_fp), _fp, _fp, _fp,
+                                           _u32p, _u8p, C.c_uint32, C.c_int, C.POINTER(_fp)]
+        L.hfo_adjoint_batch.restype = C.c_int
+        L.hfo_adjoint_batch.argtypes = [C.c_void_p, C.c_int64, C.POINTER(_fp), _fp, _fp, _fp,
+                                        _u32p, _u8p, C.c_uint32, C.c_int, C.POINTER(_fp), _fp,
+                                        C.POINTER(_fp), C.POINTER(_fp)]
+        L.hfo_make_sine_heights.argtypes = [C.c_int, C.c_int, C.c_float, C.c_float, _fp]
+        L.hfo_sample_tea_32.argtypes = [C.c_uint32, C.c_uint32, C.c_int, _u32p]
+        _lib = L
+    return _lib
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _p(a):
+    return a.ctypes.data_as(_fp)
+
+
+def invert_affine(m):
+    """Inverse of a row-major 3x4 affine matrix, computed in float64 then rounded."""
+    m = np.asarray(m, dtype=np.float64).reshape(3, 4)
+    a = np.eye(4)
+    a[:3, :] = m
+    return np.linalg.inv(a)[:3, :].astype(np.float32)
+
+
+class OracleField:
+    """Scalar CPU heightfield (oracle).  rays: float32 array [7, n] = ox,oy,oz,dx,dy,dz,maxt."""
+
+    def __init__(self, heights, max_height=1.0, to_world=None, to_object=None, flip_normals=False):
+        h = _f32(heights)
+        assert h.ndim == 2
+        self.H, self.W = h.shape
+        self.to_world = _f32(np.eye(4)[:3] if to_world is None else to_world).reshape(3, 4)
+        self.to_object = (invert_affine(self.to_world) if to_object is None
+                          else _f32(to_object).reshape(3, 4))
+        self.max_height = float(max_height)
+        self._h = lib().hfo_create(self.W, self.H, _p(h), self.max_height,
+                                   _p(self.to_world), _p(self.to_object), int(flip_normals))
+        if not self._h:
+            raise ValueError("hfo_create failed (need W,H >= 2)")
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().hfo_destroy(self._h)
+            self._h = None
+
+    def set_heights(self, heights):
+        h = _f32(heights)
+        assert h.shape == (self.H, self.W)
+        lib().hfo_set_heights(self._h, _p(h))
+
+    def num_levels(self):
+        return lib().hfo_num_levels(self._h)
+
+    def mip(self, level):
+        w, h = C.c_int(), C.c_int()
+        n = lib().hfo_get_mip(self._h, level, None, C.byref(w), C.byref(h))
+        out = np.empty((h.value, w.value, 2), np.float32)
+        lib().hfo_get_mip(self._h, level, _p(out), C.byref(w), C.byref(h))
+        assert n == w.value * h.value
+        return out
+
+    def bbox(self):
+        out = np.empty(6, np.float32)
+        lib().hfo_bbox(self._h, _p(out))
+        return out
+
+    def vertex(self, i, j):
+        out = np.empty(3, np.float32)
+        lib().hfo_vertex(self._h, i, j, _p(out))
+        return out
+
+    @staticmethod
+    def _rays(rays):
+        r = _f32(rays)
+        assert r.ndim == 2 and r.shape[0] == 7
+        arr = (_fp * 7)(*[_p(r[k]) for k in range(7)])
+        return r, arr
+
+    @staticmethod
+    def _mask(active, n):
+        if active is None:
+            return None, None
+        a = np.ascontiguousarray(active, dtype=np.uint8)
+        assert a.shape == (n,)
+        return a, a.ctypes.data_as(_u8p)
+
+    def ray_intersect_preliminary(self, rays, active=None, naive=False, nthreads=0):
+        r, arr = self._rays(rays)
+        n = r.shape[1]
+        a, ap = self._mask(active, n)
+        t = np.empty(n, np.float32); u = np.empty(n, np.float32); v = np.empty(n, np.float32)
+        prim = np.empty(n, np.uint32)
+        lib().hfo_intersect_batch(self._h, n, arr, ap, int(naive), nthreads, _p(t), _p(u), _p(v),
+                                  prim.ctypes.data_as(_u32p))
+        return t, u, v, prim
+
+    def ray_test(self, rays, active=None, naive=False, nthreads=0):
+        r, arr = self._rays(rays)
+        n = r.shape[1]
+        a, ap = self._mask(active, n)
+        hit = np.empty(n, np.uint8)
+        lib().hfo_ray_test_batch(self._h, n, arr, ap, int(naive), nthreads, hit.ctypes.data_as(_u8p))
+        return hit.astype(bool)
+
+    def compute_surface_interaction(self, rays, t, u, v, prim, ray_flags=RAY_ALL, active=None,
+                                    nthreads=0):
+        r, arr = self._rays(rays)
+        n = r.shape[1]
+        a, ap = self._mask(active, n)
+        t, u, v = _f32(t), _f32(u), _f32(v)
+        prim = np.ascontiguousarray(prim, dtype=np.uint32)
+        out = {name: np.zeros((c, n), np.float32) for name, c in SI_FIELDS}
+        ptrs = []
+        for name, c in SI_FIELDS:
+            ptrs += [_p(out[name][k]) for k in range(c)]
+        rc = lib().hfo_compute_si_batch(self._h, n, arr, _p(t), _p(u), _p(v),
+                                        prim.ctypes.data_as(_u32p), ap, ray_flags, nthreads,
+                                        (_fp * 28)(*ptrs))
+        if rc != 0:
+            raise RuntimeError("Invalid combination of RayFlags: DetachShape | FollowShape")
+        for name, c in SI_FIELDS:
+            if c == 1:
+                out[name] = out[name][0]
+        return out
+
+    def adjoint(self, rays, t, u, v, prim, grads, ray_flags=RAY_ALL, active=None, nthreads=0,
+                ray_grads=False):
+        """grads: dict field -> array ([c, n] or [n]); missing fields are zero.
+        Returns grad_heights [H, W] (and grad_o, grad_d [3, n] if ray_grads)."""
+        r, arr = self._rays(rays)
+        n = r.shape[1]
+        a, ap = self._mask(active, n)
+        t, u, v = _f32(t), _f32(u), _f32(v)
+        prim = np.ascontiguousarray(prim, dtype=np.uint32)
+        keep, ptrs = [], []
+        for name, c in GRAD_FIELDS:
+            g = grads.get(name)
+            if g is None:
+                ptrs += [None] * c
+            else:
+                g = _f32(g).reshape(c, n)
+                keep.append(g)
+                ptrs += [_p(g[k]) for k in range(c)]
+        gh = np.zeros((self.H, self.W), np.float32)
+        go = np.zeros((3, n), np.float32); gd = np.zeros((3, n), np.float32)
+        goa = (_fp * 3)(*[_p(go[k]) for k in range(3)]) if ray_grads else None
+        gda = (_fp * 3)(*[_p(gd[k]) for k in range(3)]) if ray_grads else None
+        rc = lib().hfo_adjoint_batch(self._h, n, arr, _p(t), _p(u), _p(v),
+                                     prim.ctypes.data_as(_u32p), ap, ray_flags, nthreads,
+                                     (_fp * 18)(*ptrs), _p(gh), goa, gda)
+        if rc != 0:
+            raise RuntimeError("Invalid combination of RayFlags: DetachShape | FollowShape")
+        return (gh, go, gd) if ray_grads else gh
+
+
+def make_sine_heights(W, H, fx, fy):
+    out = np.empty((H, W), np.float32)
+    lib().hfo_make_sine_heights(W, H, fx, fy, _p(out))
+    return out
+
+
+def sample_tea_32(v0, v1, rounds=4):
+    out = (C.c_uint32 * 2)()
+    lib().hfo_sample_tea_32(v0, v1, rounds, out)
+    return int(out[0]), int(out[1])
