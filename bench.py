@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mrays/s, forward + adjoint, on an N x N heightfield.
+
+One step = one pass of the hot path over one ray wavefront:
+    forward  : hf_ray_intersect  (hierarchical traversal + fused surface interaction, RayFlags::All)
+    adjoint  : hf_adjoint        (reverse mode of the SI, atomic scatter of dL/dheight)
+               [+ one RCCL all-reduce of the N x N gradient texture when world_size > 1]
+Workload (BASELINE.json configs[3] / SURVEY.md 8d): 4096^2 procedural sine heightfield,
+1024x1024 orthographic sensor @ 64 spp = 67 108 864 rays per GPU; at N > 1 every rank traces
+its own 64 spp of the same image (rays shard over pixels x spp; weak scaling), heights and
+mips are replicated and the gradient texture is summed with one all-reduce per step.
+
+Launch:  python bench.py [--gpus N --steps K --warmup W]
+         python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# contract figures, SURVEY.md section 8(d)
+FWD_BYTES_PER_RAY = 104.0   # 28 ray in + 72 SI out + 4 prim_index out
+ADJ_BYTES_PER_RAY = 128.0   # 28 ray + 16 pi + 72 upstream in + 12 atomically added
+GRID_BYTES_PER_TEXEL = 20.0 / 3.0  # heights 4 B + mips ~8/3 B, read once per pass
+HBM_PEAK_GBS = 8000.0       # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--grid", type=int, default=4096, help="heightfield resolution N (N x N)")
+    ap.add_argument("--film", type=int, default=1024)
+    ap.add_argument("--spp", type=int, default=64)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline time (0 = skip)")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    import hf_amd
+    from hf_amd import _capi
+    from hf_amd.shape import _DIFF_ROWS, _fill, _rows
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    N, Wf, spp = args.grid, args.film, args.spp
+    R = Wf * Wf * spp
+    lib = _capi.lib()
+
+    # ---- inputs, resident in HBM before any timed region --------------------------------
+    heights = hf_amd.workload.sine_heights(N, N, device=dev)
+    shape = hf_amd.Heightfield(heightfield=heights, max_height=0.5)
+    rays = hf_amd.workload.ortho_rays(Wf, Wf, spp, dev, seed=rank)      # [7, R]
+    t = torch.empty(R, dtype=torch.float32, device=dev)
+    uv = torch.empty((2, R), dtype=torch.float32, device=dev)
+    prim = torch.empty(R, dtype=torch.int32, device=dev)
+    si = torch.empty((18, R), dtype=torch.float32, device=dev)           # t,p,n,uv,sh_n,dp_du,dp_dv = 72 B/ray
+    gsi = torch.zeros((18, R), dtype=torch.float32, device=dev)          # upstream dL/dsi, 72 B/ray
+    grad_h = torch.zeros((N, N), dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    r_s = shape._rays_struct(rays[0:3], rays[3:6], rays[6])
+    pi_s = shape._pi_struct(t, uv, prim)
+    si_s = _fill(_capi.hf_si_t(), _DIFF_ROWS, _rows(si, R))
+    g_s = _fill(_capi.hf_si_grad_t(), _DIFF_ROWS, _rows(gsi, R))
+    flags = int(hf_amd.RayFlags.All)
+
+    def forward():
+        _capi.check(lib.hf_ray_intersect(shape._h, R, C.byref(r_s), flags, None, C.byref(pi_s), C.byref(si_s), stream))
+
+    def adjoint():
+        grad_h.zero_()
+        _capi.check(lib.hf_adjoint(shape._h, R, C.byref(r_s), C.byref(pi_s), flags, None, C.byref(g_s),
+                                   grad_h.data_ptr(), None, None, stream))
+        if world > 1:
+            dist.all_reduce(grad_h)
+
+    # closed-form upstream gradient of SURVEY 8d: dL/dt = 1, dL/dp = n, rest 0
+    forward()
+    torch.cuda.synchronize()
+    hit = torch.isfinite(si[0])
+    gsi[0] = hit.to(torch.float32)
+    gsi[1:4] = si[4:7] * hit
+    hit_frac = float(hit.float().mean())
+    del hit
+
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    fwd_ev, adj_ev = [], []
+
+    def step(record):
+        if record:
+            a, b, c = ev(), ev(), ev()
+            a.record(); forward(); b.record(); adjoint(); c.record()
+            fwd_ev.append((a, b)); adj_ev.append((b, c))
+        else:
+            forward(); adjoint()
+
+    for _ in range(args.warmup):
+        step(False)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    ms_step = 1e3 * elapsed / args.steps
+    total_rays = float(R) * world
+    value = total_rays / (elapsed / args.steps) / 1e6  # Mrays/s, whole job
+    fwd_ms = sum(a.elapsed_time(b) for a, b in fwd_ev) / len(fwd_ev)
+    adj_ms = sum(a.elapsed_time(b) for a, b in adj_ev) / len(adj_ev)
+
+    # gradient sanity (size-independent property): grad is finite and non-zero
+    gnorm = float(torch.linalg.norm(grad_h.double()))
+    assert math.isfinite(gnorm) and gnorm > 0
+
+    out = None
+    if rank == 0:
+        # roofline of the dominant kernel (forward traversal+SI, hf_trace_kernel<2>)
+        fwd_bytes = R * FWD_BYTES_PER_RAY + N * N * GRID_BYTES_PER_TEXEL
+        adj_bytes = R * ADJ_BYTES_PER_RAY + N * N * 4.0
+        dom_ms, dom_bytes, dom_name = (fwd_ms, fwd_bytes, "hf_trace_kernel<2>") if fwd_ms >= adj_ms else \
+                                      (adj_ms, adj_bytes, "hf_adjoint_kernel")
+        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(dom_name, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                    "avg_launch_ms": round(dom_ms, 4),
+                    "fwd_ms": round(fwd_ms, 4), "adj_ms": round(adj_ms, 4),
+                    "fwd_adj_frac": round(((fwd_bytes + adj_bytes) / ((fwd_ms + adj_ms) * 1e-3) / 1e9) / HBM_PEAK_GBS, 5)}
+        cpu = None
+        if world == 1 and args.cpu_seconds > 0:
+            cpu = cpu_baseline(args, heights.cpu().numpy(), rays, gsi, R)
+        out = {"metric": "Mrays/s forward+adjoint on 4096^2 heightfield", "value": round(value, 2),
+               "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": f"{N}x{N} sine heightfield, {Wf}x{Wf} orthographic sensor @{spp}spp "
+                                      f"= {R} rays/GPU, forward(ray_intersect, RayFlags.All)+adjoint(dL/dheight)",
+                          "rays_per_gpu": R, "hit_fraction": round(hit_frac, 4),
+                          "parallelism": f"rays sharded over {world} GPU(s), 1 all-reduce of the grad texture"},
+               "roofline": roofline, "cpu_baseline": cpu}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return out
+
+
+def cpu_baseline(args, heights_np, rays, gsi, R):
+    """CPU restatement of the reference's scalar path (oracle; the reference llvm_ad_rgb
+    heightfield cannot be built -- no source, no Dr.Jit) on a bounded strided sample."""
+    import numpy as np
+    from oracle import hf_oracle as O
+    cores = os.cpu_count() or 1
+    f = O.OracleField(heights_np, max_height=0.5)
+    grid_flags = O.RAY_ALL
+
+    def run(k):
+        stride = max(1, R // k)
+        idx = slice(0, stride * k, stride)
+        r = rays[:, idx].cpu().numpy()
+        g = gsi[:, idx].cpu().numpy()
+        grads = {"t": g[0:1], "p": g[1:4]}
+        t0 = time.perf_counter()
+        t, u, v, prim = f.ray_intersect_preliminary(r, nthreads=cores)
+        f.compute_surface_interaction(r, t, u, v, prim, grid_flags, nthreads=cores)
+        f.adjoint(r, t, u, v, prim, grads, grid_flags, nthreads=cores)
+        return time.perf_counter() - t0, r.shape[1]
+
+    dt, k = run(1 << 18)                       # calibration
+    rate = k / dt
+    k2 = int(min(R, max(1 << 18, rate * args.cpu_seconds)))
+    dt2, k2 = run(k2)
+    return {"value": round(k2 / dt2 / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "sample": f"{k2} rays, every {max(1, R // k2)}-th ray of the wavefront, forward (traversal+SI) + adjoint, "
+                      f"{dt2:.1f} s, OpenMP over rays",
+            "note": "CPU restatement of the reference scalar path (reference llvm_ad_rgb unavailable offline)"}
+
+
+if __name__ == "__main__":
+    main()

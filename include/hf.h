@@ -1,0 +1,217 @@
+/*
+ * hf.h -- C ABI of libhf: MI355X (gfx950) differentiable heightfield intersector.
+ *
+ * This is the drop-in boundary for the reference's Shape plugin interface on
+ * the heightfield hot path.  A Mitsuba 3.3 `Shape`
+ * subclass ("heightfield" plugin) forwards whole ray
+ * wavefronts through these entry points instead of running per-lane Dr.Jit
+ * code / vcalls.  Plain C types only: device pointers + sizes, no torch,
+ * no Dr.Jit, no C++ types.
+ *
+ * Conventions
+ *   - All array arguments are DEVICE pointers (HIP) to SoA component arrays
+ *     of `n` elements each (Dr.Jit arrays are SoA: one array per scalar
+ *     component, cf. the RayHitT offsets in src/render/scene_native.inl:106-113).
+ *   - Every call is asynchronous and ordered on the caller's `stream`
+ *     (a hipStream_t passed as void*; NULL = default stream).  No hidden
+ *     synchronisation except where stated (hf_bbox, hf_get_mip).
+ *   - `active` (uint8 per lane, NULL = all lanes active) mirrors the `Mask active`
+ *     argument of the reference methods; inactive lanes produce a miss /
+ *     zero-initialised record (include/mitsuba/render/interaction.h:479-499, 667-673).
+ *   - Return value: HF_OK or an error code; hf_last_error_string() describes
+ *     the last failure on the calling thread.  No exceptions cross the ABI;
+ *     the adapter turns codes into Throw(...) (src/render/mesh.cpp:711 style).
+ *   - Query functions are re-entrant on a const handle (the reference calls
+ *     them concurrently from worker threads, src/render/integrator.cpp:161-200);
+ *     hf_set_heights* requires that no query on the same handle is in flight
+ *     on another stream (reference: dr::sync_thread() in parameters_changed,
+ *     src/shapes/rectangle.cpp:131-142).
+ */
+#ifndef HF_H
+#define HF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HF_VERSION 1
+
+/* status codes */
+enum {
+    HF_OK      = 0,
+    HF_EINVAL  = 1,  /* bad argument (NULL pointer, width/height < 2: src/textures/bitmap.cpp:280-283) */
+    HF_EDEVICE = 2,  /* HIP runtime error */
+    HF_ENOMEM  = 3,  /* device allocation failed */
+    HF_EFLAGS  = 4   /* DetachShape | FollowShape (src/render/mesh.cpp:709-711) */
+};
+
+/* RayFlags -- identical values to include/mitsuba/render/interaction.h:19-69 */
+enum {
+    HF_RAY_EMPTY         = 0x0,
+    HF_RAY_MINIMAL       = 0x1,
+    HF_RAY_UV            = 0x2,
+    HF_RAY_DPDUV         = 0x4,
+    HF_RAY_SHADINGFRAME  = 0x8,
+    HF_RAY_DNGDUV        = 0x10,
+    HF_RAY_DNSDUV        = 0x20,
+    HF_RAY_BOUNDARYTEST  = 0x40,
+    HF_RAY_FOLLOWSHAPE   = 0x80,
+    HF_RAY_DETACHSHAPE   = 0x100,
+    HF_RAY_ALL           = 0x2 | 0x4 | 0x8,
+    HF_RAY_ALL_NONDIFF   = 0x2 | 0x4 | 0x8 | 0x100
+};
+
+typedef struct hf_field hf_field_t; /* opaque handle: owns heights copy, min/max mips */
+typedef void *hf_stream_t;          /* hipStream_t */
+
+/* Plugin properties (build decision, SURVEY.md section 8a: {to_world, max_height,
+ * heightfield tensor, flip_normals}); replaces the Properties-driven constructor +
+ * update() of a shape plugin (src/shapes/rectangle.cpp:83-112). */
+typedef struct hf_desc {
+    uint32_t width;        /* vertices along object x (tensor columns), >= 2 */
+    uint32_t height;       /* vertices along object y (tensor rows),    >= 2 */
+    float    max_height;   /* object z = height value * max_height */
+    float    to_world[12]; /* row-major 3x4 affine */
+    float    to_object[12];/* inverse of to_world; used when has_to_object != 0
+                              (the adapter passes Mitsuba's own m_to_object,
+                              rectangle.cpp:102), else computed by hf_invert_affine */
+    int32_t  has_to_object;
+    int32_t  flip_normals;
+    int32_t  device;       /* HIP device ordinal */
+} hf_desc_t;
+
+/* Ray3f (include/mitsuba/core/ray.h:24-82): o, d, maxt.  time/wavelengths are
+ * not used by a static shape and stay on the caller's side. */
+typedef struct hf_rays {
+    const float *o[3];
+    const float *d[3];
+    const float *maxt;
+} hf_rays_t;
+
+/* PreliminaryIntersection3f (interaction.h:587-691): t (+inf = miss), prim_uv,
+ * prim_index = 2*(cell_y*(width-1)+cell_x)+tri.  shape_index is always
+ * (uint32_t)-1 for a non-instanced shape (rectangle.cpp:222) and is not stored. */
+typedef struct hf_pi {
+    float    *t;
+    float    *prim_uv[2];
+    uint32_t *prim_index;
+} hf_pi_t;
+
+typedef struct hf_pi_const {
+    const float    *t;
+    const float    *prim_uv[2];
+    const uint32_t *prim_index;
+} hf_pi_const_t;
+
+/* SurfaceInteraction3f fields filled by Shape::compute_surface_interaction +
+ * finalize_surface_interaction (interaction.h:175-507).  Any pointer may be NULL
+ * (field not wanted).  dn_du/dn_dv are identically zero (flat shading) and
+ * duv_dx/duv_dy are zeroed by finalize; neither is stored. */
+typedef struct hf_si {
+    float *t;
+    float *p[3];
+    float *n[3];
+    float *uv[2];
+    float *sh_n[3];      /* sh_frame.n */
+    float *dp_du[3];
+    float *dp_dv[3];
+    float *boundary_test;/* written only with HF_RAY_BOUNDARYTEST */
+    float *sh_s[3];      /* sh_frame.s, sh_frame.t: HF_RAY_SHADINGFRAME (interaction.h:257-267) */
+    float *sh_t[3];
+    float *wi[3];
+} hf_si_t;
+
+/* Upstream gradient dL/d(si field); NULL pointer = zero gradient. */
+typedef struct hf_si_grad {
+    const float *t;
+    const float *p[3];
+    const float *n[3];
+    const float *uv[2];
+    const float *sh_n[3];
+    const float *dp_du[3];
+    const float *dp_dv[3];
+} hf_si_grad_t;
+
+/* ---- lifetime / parameters ------------------------------------------------ */
+
+/* Replaces: plugin construction + update() (src/shapes/rectangle.cpp:83-112) and the
+ * OptiX blob upload optix_prepare_geometry (rectangle.cpp:328-338).  Heights start
+ * as all zero; call hf_set_heights* before tracing. */
+int hf_create(const hf_desc_t *desc, hf_field_t **out);
+int hf_destroy(hf_field_t *hf);
+
+/* Replaces: parameters_changed({"heightfield"}) (pattern rectangle.cpp:131-142,
+ * tensor form src/textures/bitmap.cpp:272-286) + the accel rebuild it triggers
+ * (src/render/scene.cpp:343-385): copies width*height floats (row-major, row 0 at
+ * object y=-1) from DEVICE memory and rebuilds the min/max mip pyramid, all on `stream`. */
+int hf_set_heights(hf_field_t *hf, const float *d_heights, hf_stream_t stream);
+/* same from HOST memory (synchronous copy) */
+int hf_set_heights_host(hf_field_t *hf, const float *h_heights, hf_stream_t stream);
+/* Replaces: m_to_world update + update() (rectangle.cpp:101-112, 131-142). */
+int hf_set_transform(hf_field_t *hf, const float to_world[12], const float *to_object_or_null);
+
+/* Replaces: Shape::bbox() (include/mitsuba/render/shape.h:253; analog rectangle.cpp:114-124).
+ * World-space {min xyz, max xyz}.  Synchronises `stream`-ordered height updates. */
+int hf_bbox(hf_field_t *hf, float out[6]);
+
+/* device pointer to the handle's own copy of the heights (width*height floats) */
+int hf_heights_device(hf_field_t *hf, const float **out);
+int hf_dims(const hf_field_t *hf, uint32_t *width, uint32_t *height);
+
+/* ---- the hot path ------------------------------------------------------------ */
+
+/* Replaces: Shape::ray_intersect_preliminary(const Ray3f&, Mask)
+ * (include/mitsuba/render/shape.h:137-138, wrapper shape.h:621-629; called from
+ * include/mitsuba/render/kdtree.h:2509-2510 and src/render/shape.cpp:211). */
+int hf_ray_intersect_preliminary(const hf_field_t *hf, size_t n, const hf_rays_t *rays,
+                                 const uint8_t *active, const hf_pi_t *out,
+                                 hf_stream_t stream);
+
+/* Replaces: Shape::ray_test(const Ray3f&, Mask) (shape.h:153, 630-633;
+ * semantics == ray_intersect_preliminary().is_valid(), src/render/shape.cpp:430-434). */
+int hf_ray_test(const hf_field_t *hf, size_t n, const hf_rays_t *rays,
+                const uint8_t *active, uint8_t *out_hit, hf_stream_t stream);
+
+/* Replaces: Shape::compute_surface_interaction(ray, pi, ray_flags, recursion_depth=0, active)
+ * (shape.h:179-183) followed by SurfaceInteraction::finalize_surface_interaction
+ * (interaction.h:476-499), i.e. PreliminaryIntersection::compute_surface_interaction
+ * (interaction.h:658-684). */
+int hf_compute_surface_interaction(const hf_field_t *hf, size_t n, const hf_rays_t *rays,
+                                   const hf_pi_const_t *pi, uint32_t ray_flags,
+                                   const uint8_t *active, const hf_si_t *out,
+                                   hf_stream_t stream);
+
+/* Replaces: Shape::ray_intersect(ray, ray_flags, active) = preliminary + SI
+ * (src/render/shape.cpp:436-446); one fused kernel.  out_pi may be NULL. */
+int hf_ray_intersect(const hf_field_t *hf, size_t n, const hf_rays_t *rays,
+                     uint32_t ray_flags, const uint8_t *active,
+                     const hf_pi_t *out_pi, const hf_si_t *out_si, hf_stream_t stream);
+
+/* Replaces: the Dr.Jit reverse-mode pass through compute_surface_interaction that
+ * dr.backward_from() triggers (src/python/python/ad/integrators/prb_reparam.py:586-587):
+ * every dr::gather from the parameter buffer becomes scatter_reduce(Add).
+ * Accumulates dL/dheight (width*height floats, row-major) with float atomics;
+ * grad_o / grad_d (3 arrays each, may be NULL) receive dL/d(ray.o), dL/d(ray.d)
+ * per lane (overwritten).  grad_heights may be NULL when only ray gradients are wanted. */
+int hf_adjoint(const hf_field_t *hf, size_t n, const hf_rays_t *rays,
+               const hf_pi_const_t *pi, uint32_t ray_flags, const uint8_t *active,
+               const hf_si_grad_t *grad_si, float *grad_heights,
+               float *const grad_o[3], float *const grad_d[3], hf_stream_t stream);
+
+/* ---- introspection (tests / tools) --------------------------------------------- */
+int hf_num_levels(const hf_field_t *hf);
+/* copies mip level `level` (1..num_levels) to HOST memory as (min,max) pairs,
+ * row-major w x h; out may be NULL to query w,h.  Synchronises. */
+int hf_get_mip(const hf_field_t *hf, int level, float *h_out, uint32_t *w, uint32_t *h);
+/* inverse of a row-major 3x4 affine matrix (double precision, rounded to float) */
+int hf_invert_affine(const float in[12], float out[12]);
+const char *hf_last_error_string(void);
+int hf_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HF_H */

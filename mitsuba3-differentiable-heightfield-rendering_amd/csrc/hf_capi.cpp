@@ -1,0 +1,309 @@
+// hf_capi.cpp -- the C ABI of libhf (include/hf.h): handle management, argument
+// validation, error strings.  All device work is in hf_kernels.hip.
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "hf_launch.h"
+
+struct hf_field {
+    hf_dev_field dev;   // device view handed to kernels by value
+    float *d_heights;   // owned copy of the heights
+    float2 *d_mip;      // owned min/max pyramid
+    size_t mip_nodes;
+    int device;
+    hipEvent_t built;   // completion of the last hf_set_heights*
+};
+
+static thread_local char g_err[512] = "no error";
+
+static int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HF_HIP(call)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return fail(e_ == hipErrorOutOfMemory ? HF_ENOMEM : HF_EDEVICE, "%s: %s", #call,     \
+                        hipGetErrorString(e_));                                                   \
+    } while (0)
+
+extern "C" const char *hf_last_error_string(void) { return g_err; }
+extern "C" int hf_version(void) { return HF_VERSION; }
+
+// inverse of [A | t] = [A^-1 | -A^-1 t], adjugate formula in double
+extern "C" int hf_invert_affine(const float in[12], float out[12]) {
+    if (!in || !out) return fail(HF_EINVAL, "hf_invert_affine: NULL argument");
+    double a[3][3], t[3];
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) a[r][c] = in[4 * r + c];
+        t[r] = in[4 * r + 3];
+    }
+    double c00 = a[1][1] * a[2][2] - a[1][2] * a[2][1], c01 = a[1][2] * a[2][0] - a[1][0] * a[2][2],
+           c02 = a[1][0] * a[2][1] - a[1][1] * a[2][0];
+    double det = a[0][0] * c00 + a[0][1] * c01 + a[0][2] * c02;
+    if (det == 0.0 || !isfinite(det)) return fail(HF_EINVAL, "hf_invert_affine: singular to_world");
+    double inv[3][3];
+    inv[0][0] = c00 / det;
+    inv[0][1] = (a[0][2] * a[2][1] - a[0][1] * a[2][2]) / det;
+    inv[0][2] = (a[0][1] * a[1][2] - a[0][2] * a[1][1]) / det;
+    inv[1][0] = c01 / det;
+    inv[1][1] = (a[0][0] * a[2][2] - a[0][2] * a[2][0]) / det;
+    inv[1][2] = (a[0][2] * a[1][0] - a[0][0] * a[1][2]) / det;
+    inv[2][0] = c02 / det;
+    inv[2][1] = (a[0][1] * a[2][0] - a[0][0] * a[2][1]) / det;
+    inv[2][2] = (a[0][0] * a[1][1] - a[0][1] * a[1][0]) / det;
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) out[4 * r + c] = (float) inv[r][c];
+        out[4 * r + 3] = (float) -(inv[r][0] * t[0] + inv[r][1] * t[1] + inv[r][2] * t[2]);
+    }
+    return HF_OK;
+}
+
+static int set_transform(hf_field *hf, const float *to_world, const float *to_object) {
+    memcpy(hf->dev.to_world, to_world, sizeof(float) * 12);
+    if (to_object) {
+        memcpy(hf->dev.to_object, to_object, sizeof(float) * 12);
+        return HF_OK;
+    }
+    return hf_invert_affine(to_world, hf->dev.to_object);
+}
+
+extern "C" int hf_create(const hf_desc_t *desc, hf_field_t **out) {
+    if (!desc || !out) return fail(HF_EINVAL, "hf_create: NULL argument");
+    *out = nullptr;
+    if (desc->width < 2 || desc->height < 2)
+        return fail(HF_EINVAL, "hf_create: heightfield resolution must be at least 2x2 (got %ux%u)", desc->width,
+                    desc->height);
+    if ((uint64_t) (desc->width - 1) * (desc->height - 1) >= (1ull << 31))
+        return fail(HF_EINVAL, "hf_create: too many cells for a 32-bit prim_index");
+    int ndev = 0;
+    HF_HIP(hipGetDeviceCount(&ndev));
+    if (desc->device < 0 || desc->device >= ndev)
+        return fail(HF_EDEVICE, "hf_create: device %d not available (%d devices)", desc->device, ndev);
+    HF_HIP(hipSetDevice(desc->device));
+
+    hf_field *hf = (hf_field *) calloc(1, sizeof(hf_field));
+    if (!hf) return fail(HF_ENOMEM, "hf_create: host allocation failed");
+    hf->device = desc->device;
+    hf_dev_field &d = hf->dev;
+    d.W = (int) desc->width; d.H = (int) desc->height;
+    d.s = desc->max_height;
+    d.sx = 2.0f / (float) (d.W - 1); d.sy = 2.0f / (float) (d.H - 1);
+    d.iu = 1.0f / (float) (d.W - 1); d.iv = 1.0f / (float) (d.H - 1);
+    d.flip = desc->flip_normals ? 1 : 0;
+    int rc = set_transform(hf, desc->to_world, desc->has_to_object ? desc->to_object : nullptr);
+    if (rc != HF_OK) { free(hf); return rc; }
+
+    const int cw = d.W - 1, ch = d.H - 1;
+    int top = 0;
+    while ((1 << top) < cw || (1 << top) < ch) ++top;
+    if (top >= HF_MAX_LEVELS) { free(hf); return fail(HF_EINVAL, "hf_create: grid too large"); }
+    d.top = top;
+    d.nlev = top > 1 ? top : 1;
+    size_t off = 0;
+    for (int l = 1; l <= d.nlev; ++l) {
+        d.mw[l] = (cw + (1 << l) - 1) >> l;
+        d.mh[l] = (ch + (1 << l) - 1) >> l;
+        d.moff[l] = (uint32_t) off;
+        off += (size_t) d.mw[l] * d.mh[l];
+    }
+    hf->mip_nodes = off;
+    hipError_t e = hipMalloc((void **) &hf->d_heights, sizeof(float) * (size_t) d.W * d.H);
+    if (e == hipSuccess) e = hipMalloc((void **) &hf->d_mip, sizeof(float2) * off);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&hf->built, hipEventDisableTiming);
+    if (e != hipSuccess) {
+        if (hf->d_heights) (void) hipFree(hf->d_heights);
+        if (hf->d_mip) (void) hipFree(hf->d_mip);
+        free(hf);
+        return fail(e == hipErrorOutOfMemory ? HF_ENOMEM : HF_EDEVICE, "hf_create: %s", hipGetErrorString(e));
+    }
+    d.h = hf->d_heights;
+    d.mip = hf->d_mip;
+    // heights start as zero; build the pyramid so the handle is always traceable
+    HF_HIP(hipMemsetAsync(hf->d_heights, 0, sizeof(float) * (size_t) d.W * d.H, nullptr));
+    hf_launch_build_mips(d, hf->d_mip, nullptr);
+    HF_HIP(hipEventRecord(hf->built, nullptr));
+    HF_HIP(hipStreamSynchronize(nullptr));
+    *out = hf;
+    return HF_OK;
+}
+
+extern "C" int hf_destroy(hf_field_t *hf) {
+    if (!hf) return HF_OK;
+    (void) hipSetDevice(hf->device);
+    (void) hipDeviceSynchronize();
+    (void) hipEventDestroy(hf->built);
+    (void) hipFree(hf->d_heights);
+    (void) hipFree(hf->d_mip);
+    free(hf);
+    return HF_OK;
+}
+
+extern "C" int hf_set_heights(hf_field_t *hf, const float *d_heights, hf_stream_t stream) {
+    if (!hf || !d_heights) return fail(HF_EINVAL, "hf_set_heights: NULL argument");
+    hipStream_t st = (hipStream_t) stream;
+    const size_t bytes = sizeof(float) * (size_t) hf->dev.W * hf->dev.H;
+    if (d_heights != hf->d_heights)
+        HF_HIP(hipMemcpyAsync(hf->d_heights, d_heights, bytes, hipMemcpyDeviceToDevice, st));
+    hf_launch_build_mips(hf->dev, hf->d_mip, st);
+    HF_HIP(hipGetLastError());
+    HF_HIP(hipEventRecord(hf->built, st));
+    return HF_OK;
+}
+
+extern "C" int hf_set_heights_host(hf_field_t *hf, const float *h_heights, hf_stream_t stream) {
+    if (!hf || !h_heights) return fail(HF_EINVAL, "hf_set_heights_host: NULL argument");
+    hipStream_t st = (hipStream_t) stream;
+    const size_t bytes = sizeof(float) * (size_t) hf->dev.W * hf->dev.H;
+    HF_HIP(hipMemcpyAsync(hf->d_heights, h_heights, bytes, hipMemcpyHostToDevice, st));
+    HF_HIP(hipStreamSynchronize(st)); // the host buffer may be reused by the caller
+    return hf_set_heights(hf, hf->d_heights, stream);
+}
+
+extern "C" int hf_set_transform(hf_field_t *hf, const float to_world[12], const float *to_object_or_null) {
+    if (!hf || !to_world) return fail(HF_EINVAL, "hf_set_transform: NULL argument");
+    return set_transform(hf, to_world, to_object_or_null);
+}
+
+extern "C" int hf_heights_device(hf_field_t *hf, const float **out) {
+    if (!hf || !out) return fail(HF_EINVAL, "hf_heights_device: NULL argument");
+    *out = hf->d_heights;
+    return HF_OK;
+}
+
+extern "C" int hf_dims(const hf_field_t *hf, uint32_t *width, uint32_t *height) {
+    if (!hf) return fail(HF_EINVAL, "hf_dims: NULL argument");
+    if (width) *width = (uint32_t) hf->dev.W;
+    if (height) *height = (uint32_t) hf->dev.H;
+    return HF_OK;
+}
+
+extern "C" int hf_num_levels(const hf_field_t *hf) { return hf ? hf->dev.nlev : 0; }
+
+extern "C" int hf_get_mip(const hf_field_t *hf, int level, float *h_out, uint32_t *w, uint32_t *h) {
+    if (!hf || level < 1 || level > hf->dev.nlev) return fail(HF_EINVAL, "hf_get_mip: bad level %d", level);
+    if (w) *w = (uint32_t) hf->dev.mw[level];
+    if (h) *h = (uint32_t) hf->dev.mh[level];
+    if (h_out) {
+        HF_HIP(hipEventSynchronize(hf->built));
+        HF_HIP(hipMemcpy(h_out, hf->d_mip + hf->dev.moff[level],
+                         sizeof(float2) * (size_t) hf->dev.mw[level] * hf->dev.mh[level], hipMemcpyDeviceToHost));
+    }
+    return HF_OK;
+}
+
+// world-space box of the 8 corners of the object-space bound (analog: rectangle.cpp:114-124)
+extern "C" int hf_bbox(hf_field_t *hf, float out[6]) {
+    if (!hf || !out) return fail(HF_EINVAL, "hf_bbox: NULL argument");
+    float zr[2];
+    HF_HIP(hipEventSynchronize(hf->built));
+    HF_HIP(hipMemcpy(zr, hf->d_mip + hf->dev.moff[hf->dev.nlev], sizeof(zr), hipMemcpyDeviceToHost));
+    const hf_dev_field &d = hf->dev;
+    const float lo[3] = { fmaf(0.f, d.sx, -1.f), fmaf(0.f, d.sy, -1.f), zr[0] };
+    const float hi[3] = { fmaf((float) (d.W - 1), d.sx, -1.f), fmaf((float) (d.H - 1), d.sy, -1.f), zr[1] };
+    for (int k = 0; k < 3; ++k) { out[k] = INFINITY; out[3 + k] = -INFINITY; }
+    const float *m = d.to_world;
+    for (int c = 0; c < 8; ++c) {
+        const float p[3] = { (c & 1) ? hi[0] : lo[0], (c & 2) ? hi[1] : lo[1], (c & 4) ? hi[2] : lo[2] };
+        for (int k = 0; k < 3; ++k) {
+            float acc = m[4 * k + 3];
+            acc = fmaf(m[4 * k + 0], p[0], acc);
+            acc = fmaf(m[4 * k + 1], p[1], acc);
+            acc = fmaf(m[4 * k + 2], p[2], acc);
+            out[k] = fminf(out[k], acc);
+            out[3 + k] = fmaxf(out[3 + k], acc);
+        }
+    }
+    return HF_OK;
+}
+
+static int check_rays(const char *fn, const hf_field_t *hf, size_t n, const hf_rays_t *rays) {
+    if (!hf || !rays) return fail(HF_EINVAL, "%s: NULL argument", fn);
+    if (n == 0) return HF_OK;
+    for (int k = 0; k < 3; ++k)
+        if (!rays->o[k] || !rays->d[k]) return fail(HF_EINVAL, "%s: NULL ray component array", fn);
+    if (!rays->maxt) return fail(HF_EINVAL, "%s: NULL ray maxt array", fn);
+    return HF_OK;
+}
+
+static int check_flags(const char *fn, uint32_t flags) {
+    if ((flags & HF_RAY_DETACHSHAPE) && (flags & HF_RAY_FOLLOWSHAPE))
+        return fail(HF_EFLAGS, "%s: Invalid combination of RayFlags: DetachShape | FollowShape", fn);
+    return HF_OK;
+}
+
+static int check_pi(const char *fn, size_t n, const hf_pi_const_t *pi) {
+    if (!pi) return fail(HF_EINVAL, "%s: NULL pi", fn);
+    if (n && (!pi->t || !pi->prim_uv[0] || !pi->prim_uv[1] || !pi->prim_index))
+        return fail(HF_EINVAL, "%s: NULL preliminary-intersection array", fn);
+    return HF_OK;
+}
+
+extern "C" int hf_ray_intersect_preliminary(const hf_field_t *hf, size_t n, const hf_rays_t *rays,
+                                            const uint8_t *active, const hf_pi_t *out, hf_stream_t stream) {
+    int rc = check_rays("hf_ray_intersect_preliminary", hf, n, rays);
+    if (rc) return rc;
+    if (!out || (n && !out->t)) return fail(HF_EINVAL, "hf_ray_intersect_preliminary: NULL output");
+    hf_launch_trace(0, hf->dev, n, rays, active, out, nullptr, nullptr, 0, (hipStream_t) stream);
+    HF_HIP(hipGetLastError());
+    return HF_OK;
+}
+
+extern "C" int hf_ray_test(const hf_field_t *hf, size_t n, const hf_rays_t *rays, const uint8_t *active,
+                           uint8_t *out_hit, hf_stream_t stream) {
+    int rc = check_rays("hf_ray_test", hf, n, rays);
+    if (rc) return rc;
+    if (n && !out_hit) return fail(HF_EINVAL, "hf_ray_test: NULL output");
+    hf_launch_trace(1, hf->dev, n, rays, active, nullptr, out_hit, nullptr, 0, (hipStream_t) stream);
+    HF_HIP(hipGetLastError());
+    return HF_OK;
+}
+
+extern "C" int hf_compute_surface_interaction(const hf_field_t *hf, size_t n, const hf_rays_t *rays,
+                                              const hf_pi_const_t *pi, uint32_t ray_flags, const uint8_t *active,
+                                              const hf_si_t *out, hf_stream_t stream) {
+    int rc = check_rays("hf_compute_surface_interaction", hf, n, rays);
+    if (rc) return rc;
+    if ((rc = check_flags("hf_compute_surface_interaction", ray_flags))) return rc;
+    if ((rc = check_pi("hf_compute_surface_interaction", n, pi))) return rc;
+    if (!out) return fail(HF_EINVAL, "hf_compute_surface_interaction: NULL output");
+    hf_launch_si(hf->dev, n, rays, pi, active, out, ray_flags, (hipStream_t) stream);
+    HF_HIP(hipGetLastError());
+    return HF_OK;
+}
+
+extern "C" int hf_ray_intersect(const hf_field_t *hf, size_t n, const hf_rays_t *rays, uint32_t ray_flags,
+                                const uint8_t *active, const hf_pi_t *out_pi, const hf_si_t *out_si,
+                                hf_stream_t stream) {
+    int rc = check_rays("hf_ray_intersect", hf, n, rays);
+    if (rc) return rc;
+    if ((rc = check_flags("hf_ray_intersect", ray_flags))) return rc;
+    if (!out_si) return fail(HF_EINVAL, "hf_ray_intersect: NULL output");
+    hf_launch_trace(2, hf->dev, n, rays, active, out_pi, nullptr, out_si, ray_flags, (hipStream_t) stream);
+    HF_HIP(hipGetLastError());
+    return HF_OK;
+}
+
+extern "C" int hf_adjoint(const hf_field_t *hf, size_t n, const hf_rays_t *rays, const hf_pi_const_t *pi,
+                          uint32_t ray_flags, const uint8_t *active, const hf_si_grad_t *grad_si,
+                          float *grad_heights, float *const grad_o[3], float *const grad_d[3],
+                          hf_stream_t stream) {
+    int rc = check_rays("hf_adjoint", hf, n, rays);
+    if (rc) return rc;
+    if ((rc = check_flags("hf_adjoint", ray_flags))) return rc;
+    if ((rc = check_pi("hf_adjoint", n, pi))) return rc;
+    if (!grad_si) return fail(HF_EINVAL, "hf_adjoint: NULL grad_si");
+    if (grad_o && (!grad_o[0] || !grad_o[1] || !grad_o[2])) return fail(HF_EINVAL, "hf_adjoint: NULL grad_o array");
+    if (grad_d && (!grad_d[0] || !grad_d[1] || !grad_d[2])) return fail(HF_EINVAL, "hf_adjoint: NULL grad_d array");
+    hf_launch_adjoint(hf->dev, n, rays, pi, active, grad_si, ray_flags, grad_heights, grad_o, grad_d,
+                      (hipStream_t) stream);
+    HF_HIP(hipGetLastError());
+    return HF_OK;
+}

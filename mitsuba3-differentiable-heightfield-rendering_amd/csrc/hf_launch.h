@@ -1,0 +1,16 @@
+// hf_launch.h -- host-side launch entry points implemented in hf_kernels.hip
+#pragma once
+#include <hip/hip_runtime.h>
+#include <string.h>
+#include "../../include/hf.h"
+#include "hf_device.h"
+
+void hf_launch_build_mips(const hf_dev_field &f, float2 *mip, hipStream_t stream);
+// mode 0: closest hit -> pi; 1: any hit -> hit; 2: closest hit + fused surface interaction
+void hf_launch_trace(int mode, const hf_dev_field &f, size_t n, const hf_rays_t *rays, const uint8_t *active,
+                     const hf_pi_t *pi, uint8_t *hit, const hf_si_t *si, uint32_t flags, hipStream_t stream);
+void hf_launch_si(const hf_dev_field &f, size_t n, const hf_rays_t *rays, const hf_pi_const_t *pi,
+                  const uint8_t *active, const hf_si_t *si, uint32_t flags, hipStream_t stream);
+void hf_launch_adjoint(const hf_dev_field &f, size_t n, const hf_rays_t *rays, const hf_pi_const_t *pi,
+                       const uint8_t *active, const hf_si_grad_t *gs, uint32_t flags, float *grad_h,
+                       float *const grad_o[3], float *const grad_d[3], hipStream_t stream);

@@ -1,0 +1,481 @@
+"""Host-side mirror of the reference's Shape plugin interface for the heightfield
+hot path, on top of the C ABI (include/hf.h).  Names, argument meaning and error
+behaviour follow include/mitsuba/render/shape.h:137-183 and its Python surface
+src/render/python/shape_v.cpp:51-102; the data types follow
+include/mitsuba/core/ray.h:24-82 and include/mitsuba/render/interaction.h.
+
+torch is used for device memory, streams and autograd plumbing only; all
+arithmetic happens in the HIP kernels of libhf.so.  There is no CPU fallback.
+"""
+import ctypes as C
+import enum
+import math
+
+import torch
+
+from . import _capi
+from ._capi import check, hf_desc_t, hf_pi_t, hf_rays_t, hf_si_grad_t, hf_si_t
+
+
+class RayFlags(enum.IntFlag):
+    """include/mitsuba/render/interaction.h:19-69"""
+    Empty = 0x0
+    Minimal = 0x1
+    UV = 0x2
+    dPdUV = 0x4
+    ShadingFrame = 0x8
+    dNGdUV = 0x10
+    dNSdUV = 0x20
+    BoundaryTest = 0x40
+    FollowShape = 0x80
+    DetachShape = 0x100
+    All = 0x2 | 0x4 | 0x8
+    AllNonDifferentiable = 0x2 | 0x4 | 0x8 | 0x100
+
+
+class ParamFlags(enum.IntFlag):
+    """include/mitsuba/render/fwd / object.h ParamFlags"""
+    Differentiable = 0x0
+    NonDifferentiable = 0x1
+    Discontinuous = 0x2
+
+
+def _as_f32(x, device):
+    t = torch.as_tensor(x, dtype=torch.float32, device=device)
+    return t.contiguous()
+
+
+class Ray3f:
+    """SoA ray wavefront: o, d as [3, n] float32 tensors, maxt [n] (default +inf,
+    i.e. dr::Largest, ray.h:37).  time / wavelengths are carried but unused."""
+
+    def __init__(self, o, d, maxt=None, time=0.0, wavelengths=None):
+        dev = o.device if isinstance(o, torch.Tensor) else (d.device if isinstance(d, torch.Tensor) else "cuda")
+        self.o = _as_f32(o, dev)
+        self.d = _as_f32(d, dev)
+        if self.o.dim() == 1:
+            self.o = self.o.reshape(3, 1)
+        if self.d.dim() == 1:
+            self.d = self.d.reshape(3, 1)
+        n = max(self.o.shape[1], self.d.shape[1])
+        if self.o.shape[1] != n:
+            self.o = self.o.expand(3, n).contiguous()
+        if self.d.shape[1] != n:
+            self.d = self.d.expand(3, n).contiguous()
+        assert self.o.shape == (3, n) and self.d.shape == (3, n), "Ray3f expects [3, n] SoA tensors"
+        if maxt is None:
+            self.maxt = torch.full((n,), math.inf, dtype=torch.float32, device=self.o.device)
+        else:
+            self.maxt = _as_f32(maxt, self.o.device).reshape(-1)
+            if self.maxt.numel() == 1 and n != 1:
+                self.maxt = self.maxt.expand(n).contiguous()
+        self.time = time
+        self.wavelengths = wavelengths
+
+    def __len__(self):
+        return self.o.shape[1]
+
+    def __call__(self, t):
+        """ray(t) = fmadd(d, t, o), ray.h:57"""
+        return torch.addcmul(self.o, self.d, t)
+
+    @property
+    def device(self):
+        return self.o.device
+
+
+class Frame3f:
+    def __init__(self, s, t, n):
+        self.s, self.t, self.n = s, t, n
+
+    def to_local(self, v):
+        return torch.stack([(v * self.s).sum(0), (v * self.t).sum(0), (v * self.n).sum(0)])
+
+
+class PreliminaryIntersection3f:
+    """interaction.h:587-691"""
+
+    def __init__(self, t, prim_uv, prim_index, shape):
+        self.t = t
+        self.prim_uv = prim_uv
+        self.prim_index = prim_index
+        # (uint32_t) -1 for a non-instanced shape (rectangle.cpp:222)
+        self.shape_index = torch.full_like(prim_index, -1)
+        self.shape = shape
+        self.instance = None
+
+    def is_valid(self):
+        return self.t != math.inf
+
+    def compute_surface_interaction(self, ray, ray_flags=RayFlags.All, active=True):
+        """interaction.h:658-684: shape->compute_surface_interaction + finalize."""
+        return self.shape.compute_surface_interaction(ray, self, ray_flags, 0, active)
+
+
+class SurfaceInteraction3f:
+    """interaction.h:175-507 (fields of DRJIT_STRUCT :504-506 that a static shape fills)"""
+
+    def __init__(self):
+        self.t = self.p = self.n = self.uv = None
+        self.sh_frame = None
+        self.dp_du = self.dp_dv = self.dn_du = self.dn_dv = None
+        self.duv_dx = self.duv_dy = None
+        self.wi = None
+        self.prim_index = None
+        self.boundary_test = None
+        self.shape = None
+        self.instance = None
+        self.time = 0.0
+        self.wavelengths = None
+
+    def is_valid(self):
+        return self.t != math.inf
+
+
+# order of the differentiable SI block handed to autograd: 18 rows
+_DIFF_ROWS = [("t", 1), ("p", 3), ("n", 3), ("uv", 2), ("sh_n", 3), ("dp_du", 3), ("dp_dv", 3)]
+_AUX_ROWS = [("boundary_test", 1), ("sh_s", 3), ("sh_t", 3), ("wi", 3)]
+
+
+def _rows(buf, n):
+    """device addresses of the rows of a contiguous [k, n] float32 tensor"""
+    base = buf.data_ptr()
+    return [base + 4 * n * k for k in range(buf.shape[0])]
+
+
+def _fill(struct, layout, addrs):
+    k = 0
+    for name, c in layout:
+        if c == 1:
+            setattr(struct, name, addrs[k])
+        else:
+            arr = getattr(struct, name)
+            for j in range(c):
+                arr[j] = addrs[k + j]
+        k += c
+    return struct
+
+
+class _SurfaceInteractionOp(torch.autograd.Function):
+    """Differentiable SI block [18, n]; backward = hf_adjoint (atomic scatter of dL/dheight)."""
+
+    @staticmethod
+    def forward(ctx, shape, heights, o, d, maxt, t, uv, prim, flags, active, diff_block):
+        ctx.shape, ctx.flags, ctx.active = shape, flags, active
+        ctx.save_for_backward(o, d, maxt, t, uv, prim)
+        ctx.h_version = shape._heights_version
+        return diff_block
+
+    @staticmethod
+    def backward(ctx, g):
+        shape = ctx.shape
+        o, d, maxt, t, uv, prim = ctx.saved_tensors
+        if ctx.h_version != shape._heights_version:
+            raise RuntimeError("heightfield parameters changed between forward and backward")
+        n = o.shape[1]
+        g = g.contiguous().to(torch.float32)
+        need_h, need_o, need_d = ctx.needs_input_grad[1], ctx.needs_input_grad[2], ctx.needs_input_grad[3]
+        grad_h = torch.zeros((shape.height, shape.width), dtype=torch.float32, device=o.device) if need_h else None
+        grad_od = torch.empty((6, n), dtype=torch.float32, device=o.device) if (need_o or need_d) else None
+        shape._adjoint_raw(o, d, maxt, t, uv, prim, ctx.flags, ctx.active, g, grad_h, grad_od)
+        go = grad_od[0:3] if need_o else None
+        gd = grad_od[3:6] if need_d else None
+        return None, grad_h, go, gd, None, None, None, None, None, None, None
+
+
+class Heightfield:
+    """`heightfield` shape plugin mirror.
+
+    Properties (build decision, SURVEY.md section 8a -- the reference snapshot has no
+    heightfield plugin): `heightfield` ([H, W] or [H, W, 1] tensor, row 0 at object
+    y = -1; cf. TensorXf(data, 3, {H,W,C}) in src/textures/bitmap.cpp:262),
+    `max_height`, `to_world` (3x4 / 4x4 affine), `flip_normals`.
+    Object space is Rectangle's: x,y in [-1,1], +Z up (src/shapes/rectangle.cpp:47-48).
+    """
+
+    def __init__(self, props=None, **kw):
+        props = dict(props or {}, **kw)
+        props.pop("type", None)
+        hfield = props.pop("heightfield")
+        self.max_height = float(props.pop("max_height", 1.0))
+        to_world = props.pop("to_world", None)
+        self.flip_normals = bool(props.pop("flip_normals", False))
+        device = props.pop("device", None)
+        if props:
+            raise RuntimeError(f"Unreferenced properties: {sorted(props)}")  # Properties semantics
+        if not torch.cuda.is_available():
+            raise RuntimeError("Heightfield: no HIP device available (libhf has no CPU fallback)")
+        if device is None:
+            device = hfield.device if isinstance(hfield, torch.Tensor) and hfield.is_cuda else torch.device("cuda", torch.cuda.current_device())
+        self.device = torch.device(device)
+        h = torch.as_tensor(hfield, dtype=torch.float32)
+        if h.dim() == 3 and h.shape[2] == 1:
+            h = h[:, :, 0]
+        if h.dim() != 2:
+            raise RuntimeError("heightfield: expected a [H, W] or [H, W, 1] tensor")
+        self.height, self.width = int(h.shape[0]), int(h.shape[1])
+        tw = torch.eye(4, dtype=torch.float64)[:3] if to_world is None else torch.as_tensor(to_world, dtype=torch.float64).cpu()
+        tw = tw.reshape(-1)[:12].reshape(3, 4)
+        self.to_world = tw.to(torch.float32)
+        desc = hf_desc_t()
+        desc.width, desc.height = self.width, self.height
+        desc.max_height = self.max_height
+        for k, v in enumerate(self.to_world.reshape(-1).tolist()):
+            desc.to_world[k] = v
+        desc.has_to_object = 0
+        desc.flip_normals = int(self.flip_normals)
+        desc.device = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        handle = C.c_void_p()
+        check(_capi.lib().hf_create(C.byref(desc), C.byref(handle)))  # HF_EINVAL if H or W < 2
+        self._h = handle
+        self._dirty = True
+        self._heights_version = 0
+        # the differentiable parameter (put_parameter("heightfield", ..., Differentiable|Discontinuous))
+        self.heightfield = h.to(self.device).contiguous().clone()
+        self.parameters_changed(["heightfield"])
+
+    # ---- lifetime ---------------------------------------------------------------------
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            try:
+                _capi.lib().hf_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    # ---- parameter plumbing (shape.cpp:536-570, rectangle.cpp:126-142) ---------------
+    def traverse(self, callback):
+        callback.put_parameter("heightfield", self.heightfield, ParamFlags.Differentiable | ParamFlags.Discontinuous)
+        callback.put_parameter("max_height", self.max_height, ParamFlags.NonDifferentiable)
+        callback.put_parameter("to_world", self.to_world, ParamFlags.NonDifferentiable)
+
+    def parameters_changed(self, keys=()):
+        keys = list(keys)
+        if not keys or "heightfield" in keys:
+            h = self.heightfield
+            if h.dim() == 3 and h.shape[2] == 1:
+                h = h[:, :, 0]
+            if tuple(h.shape) != (self.height, self.width):
+                # bitmap.cpp:272-286: resolution may not change / must stay >= 2
+                raise RuntimeError(f"heightfield: tensor shape {tuple(h.shape)} != ({self.height}, {self.width})")
+            hd = h.detach().to(device=self.device, dtype=torch.float32).contiguous()
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            check(_capi.lib().hf_set_heights(self._h, hd.data_ptr(), stream))
+            self._heights_keepalive = hd
+            self._heights_version += 1
+        if not keys or "to_world" in keys:
+            tw = (C.c_float * 12)(*self.to_world.reshape(-1).tolist())
+            check(_capi.lib().hf_set_transform(self._h, tw, None))
+        self.mark_dirty()
+
+    def parameters_grad_enabled(self):
+        return bool(self.heightfield.requires_grad)
+
+    def mark_dirty(self):
+        self._dirty = True
+
+    def dirty(self):
+        return self._dirty
+
+    def primitive_count(self):
+        """one kd-tree primitive (shape.cpp:526-529); the cells are internal"""
+        return 1
+
+    def effective_primitive_count(self):
+        return 2 * (self.width - 1) * (self.height - 1)
+
+    def is_mesh(self):
+        return False
+
+    def bbox(self):
+        out = (C.c_float * 6)()
+        check(_capi.lib().hf_bbox(self._h, out))
+        return torch.tensor(list(out), dtype=torch.float32).reshape(2, 3)
+
+    def num_levels(self):
+        return _capi.lib().hf_num_levels(self._h)
+
+    def mip(self, level):
+        w, h = C.c_uint32(), C.c_uint32()
+        check(_capi.lib().hf_get_mip(self._h, level, None, C.byref(w), C.byref(h)))
+        out = torch.empty((h.value, w.value, 2), dtype=torch.float32)
+        check(_capi.lib().hf_get_mip(self._h, level, out.data_ptr(), C.byref(w), C.byref(h)))
+        return out
+
+    # ---- helpers -------------------------------------------------------------------------
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _check_ray(self, ray):
+        if not isinstance(ray, Ray3f):
+            raise TypeError("expected a Ray3f")
+        if ray.device != self.device:
+            raise RuntimeError(f"ray lives on {ray.device}, shape on {self.device}")
+
+    @staticmethod
+    def _rays_struct(o, d, maxt):
+        n = o.shape[1]
+        r = hf_rays_t()
+        for k in range(3):
+            r.o[k] = o.data_ptr() + 4 * n * k
+            r.d[k] = d.data_ptr() + 4 * n * k
+        r.maxt = maxt.data_ptr()
+        return r
+
+    def _mask(self, active, n):
+        if active is True or active is None:
+            return None, None
+        if active is False:
+            active = torch.zeros(n, dtype=torch.bool, device=self.device)
+        a = torch.as_tensor(active, device=self.device).to(torch.uint8).contiguous()
+        if a.numel() == 1 and n != 1:
+            a = a.expand(n).contiguous()
+        assert a.shape == (n,)
+        return a, a.data_ptr()
+
+    @staticmethod
+    def _pi_struct(t, uv, prim):
+        n = t.shape[0]
+        p = hf_pi_t()
+        p.t = t.data_ptr()
+        p.prim_uv[0] = uv.data_ptr()
+        p.prim_uv[1] = uv.data_ptr() + 4 * n
+        p.prim_index = prim.data_ptr()
+        return p
+
+    # ---- the hot path ---------------------------------------------------------------------
+    def ray_intersect_preliminary(self, ray, active=True):
+        """shape.h:137-138"""
+        self._check_ray(ray)
+        n = len(ray)
+        t = torch.empty(n, dtype=torch.float32, device=self.device)
+        uv = torch.empty((2, n), dtype=torch.float32, device=self.device)
+        prim = torch.empty(n, dtype=torch.int32, device=self.device)
+        keep, ap = self._mask(active, n)
+        rays = self._rays_struct(ray.o, ray.d, ray.maxt)
+        pi = self._pi_struct(t, uv, prim)
+        check(_capi.lib().hf_ray_intersect_preliminary(self._h, n, C.byref(rays), ap, C.byref(pi), self._stream()))
+        return PreliminaryIntersection3f(t, uv, prim, self)
+
+    def ray_test(self, ray, active=True):
+        """shape.h:153"""
+        self._check_ray(ray)
+        n = len(ray)
+        hit = torch.empty(n, dtype=torch.uint8, device=self.device)
+        keep, ap = self._mask(active, n)
+        rays = self._rays_struct(ray.o, ray.d, ray.maxt)
+        check(_capi.lib().hf_ray_test(self._h, n, C.byref(rays), ap, hit.data_ptr(), self._stream()))
+        return hit.bool()
+
+    def _package_si(self, ray, pi_t, pi_prim, diff, aux, ray_flags):
+        n = len(ray)
+        si = SurfaceInteraction3f()
+        si.t = diff[0]
+        si.p, si.n, si.uv = diff[1:4], diff[4:7], diff[7:9]
+        sh_n = diff[9:12]
+        si.dp_du, si.dp_dv = diff[12:15], diff[15:18]
+        si.boundary_test = aux[0] if (ray_flags & RayFlags.BoundaryTest) else torch.zeros(n, device=self.device)
+        si.sh_frame = Frame3f(aux[1:4], aux[4:7], sh_n)
+        si.wi = aux[7:10]
+        zeros3 = torch.zeros((3, n), dtype=torch.float32, device=self.device)
+        si.dn_du, si.dn_dv = zeros3, zeros3          # flat shading
+        si.duv_dx = si.duv_dy = torch.zeros((2, n), dtype=torch.float32, device=self.device)
+        si.prim_index = pi_prim                       # interaction.h:486
+        si.shape = self
+        si.time, si.wavelengths = ray.time, ray.wavelengths
+        return si
+
+    def _wants_grad(self, ray, ray_flags):
+        if not torch.is_grad_enabled():
+            return False
+        h_live = self.heightfield.requires_grad and not (ray_flags & RayFlags.DetachShape)
+        return bool(h_live or ray.o.requires_grad or ray.d.requires_grad)
+
+    def compute_surface_interaction(self, ray, pi, ray_flags=RayFlags.All, recursion_depth=0, active=True):
+        """shape.h:179-183 + finalize_surface_interaction (interaction.h:476-499)"""
+        self._check_ray(ray)
+        ray_flags = int(ray_flags)
+        n = len(ray)
+        diff = torch.empty((18, n), dtype=torch.float32, device=self.device)
+        aux = torch.empty((10, n), dtype=torch.float32, device=self.device)
+        if recursion_depth > 0:   # mesh.cpp:680-682: early exit, zero-initialised record
+            diff.zero_(); aux.zero_()
+            return self._package_si(ray, pi.t, pi.prim_index, diff, aux, ray_flags)
+        keep, ap = self._mask(active, n)
+        out = _fill(_fill(hf_si_t(), _DIFF_ROWS, _rows(diff, n)), _AUX_ROWS, _rows(aux, n))
+        rays = self._rays_struct(ray.o, ray.d, ray.maxt)
+        pis = self._pi_struct(pi.t, pi.prim_uv, pi.prim_index)
+        check(_capi.lib().hf_compute_surface_interaction(self._h, n, C.byref(rays), C.byref(pis), ray_flags, ap,
+                                                         C.byref(out), self._stream()))
+        if self._wants_grad(ray, ray_flags):
+            diff = _SurfaceInteractionOp.apply(self, self.heightfield, ray.o, ray.d, ray.maxt, pi.t, pi.prim_uv,
+                                               pi.prim_index, ray_flags, keep, diff)
+        return self._package_si(ray, pi.t, pi.prim_index, diff, aux, ray_flags)
+
+    def ray_intersect(self, ray, ray_flags=RayFlags.All, active=True):
+        """shape.cpp:436-446: preliminary intersection + surface interaction, one fused kernel"""
+        self._check_ray(ray)
+        ray_flags = int(ray_flags)
+        n = len(ray)
+        t = torch.empty(n, dtype=torch.float32, device=self.device)
+        uv = torch.empty((2, n), dtype=torch.float32, device=self.device)
+        prim = torch.empty(n, dtype=torch.int32, device=self.device)
+        diff = torch.empty((18, n), dtype=torch.float32, device=self.device)
+        aux = torch.empty((10, n), dtype=torch.float32, device=self.device)
+        keep, ap = self._mask(active, n)
+        out = _fill(_fill(hf_si_t(), _DIFF_ROWS, _rows(diff, n)), _AUX_ROWS, _rows(aux, n))
+        rays = self._rays_struct(ray.o, ray.d, ray.maxt)
+        pis = self._pi_struct(t, uv, prim)
+        check(_capi.lib().hf_ray_intersect(self._h, n, C.byref(rays), ray_flags, ap, C.byref(pis), C.byref(out),
+                                           self._stream()))
+        if self._wants_grad(ray, ray_flags):
+            diff = _SurfaceInteractionOp.apply(self, self.heightfield, ray.o, ray.d, ray.maxt, t, uv, prim,
+                                               ray_flags, keep, diff)
+        si = self._package_si(ray, t, prim, diff, aux, ray_flags)
+        si.prim_uv = uv
+        return si
+
+    # ---- adjoint ------------------------------------------------------------------------------
+    def _adjoint_raw(self, o, d, maxt, t, uv, prim, ray_flags, active_u8, g, grad_h, grad_od):
+        n = o.shape[1]
+        rays = self._rays_struct(o, d, maxt)
+        pis = self._pi_struct(t, uv, prim)
+        gs = _fill(hf_si_grad_t(), _DIFF_ROWS, _rows(g, n))
+        go = gd = None
+        if grad_od is not None:
+            rows = _rows(grad_od, n)
+            go = (C.c_void_p * 3)(*rows[0:3])
+            gd = (C.c_void_p * 3)(*rows[3:6])
+        check(_capi.lib().hf_adjoint(self._h, n, C.byref(rays), C.byref(pis), int(ray_flags),
+                                     active_u8.data_ptr() if active_u8 is not None else None, C.byref(gs),
+                                     grad_h.data_ptr() if grad_h is not None else None,
+                                     C.byref(go) if go is not None else None,
+                                     C.byref(gd) if gd is not None else None, self._stream()))
+
+    def adjoint(self, ray, pi, grad_si, ray_flags=RayFlags.All, active=True, grad_heightfield=None,
+                ray_grads=False):
+        """Explicit adjoint: accumulate dL/dheight for upstream gradients `grad_si`
+        ([18, n]: t, p, n, uv, sh_frame.n, dp_du, dp_dv) into `grad_heightfield` ([H, W])."""
+        self._check_ray(ray)
+        n = len(ray)
+        g = _as_f32(grad_si, self.device)
+        assert g.shape == (18, n)
+        if grad_heightfield is None:
+            grad_heightfield = torch.zeros((self.height, self.width), dtype=torch.float32, device=self.device)
+        keep, _ = self._mask(active, n)
+        grad_od = torch.empty((6, n), dtype=torch.float32, device=self.device) if ray_grads else None
+        self._adjoint_raw(ray.o, ray.d, ray.maxt, pi.t, pi.prim_uv, pi.prim_index, ray_flags, keep, g,
+                          grad_heightfield, grad_od)
+        if ray_grads:
+            return grad_heightfield, grad_od[0:3], grad_od[3:6]
+        return grad_heightfield
+
+
+def allreduce_gradient(grad, group=None):
+    """Sum the per-GPU dL/dheight textures (one RCCL all-reduce over xGMI; rays are
+    sharded over ranks, heights are replicated -- SURVEY.md section 8e)."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(grad, op=dist.ReduceOp.SUM, group=group)
+    return grad

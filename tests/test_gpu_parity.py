@@ -1,0 +1,182 @@
+"""GPU parity: HIP path (through the C ABI) vs the CPU oracle on the same seeded inputs.
+
+Bars (BASELINE.json north_star): prim_index / hit mask bit-exact; t, prim_uv, SI fields and
+height gradients within 1e-5 relative.  (t and prim_uv are in fact compared bit-exact
+here as well, because both sides use the same explicit operation order.)
+"""
+import numpy as np
+import pytest
+import torch
+
+import common
+
+pytestmark = pytest.mark.gpu
+REL = 1e-5
+
+
+def _mk(hf, oracle, h, max_height=0.5, to_world=None, flip=False):
+    f_o = oracle.OracleField(h, max_height=max_height, to_world=to_world, flip_normals=flip)
+    props = dict(heightfield=torch.from_numpy(h), max_height=max_height, flip_normals=flip)
+    if to_world is not None:
+        props["to_world"] = torch.from_numpy(np.asarray(to_world))
+    f_g = hf.Heightfield(props)
+    return f_o, f_g
+
+
+def _ray(hf, r):
+    rt = torch.from_numpy(r).cuda()
+    return hf.Ray3f(rt[0:3].contiguous(), rt[3:6].contiguous(), rt[6].contiguous())
+
+
+def _check_prelim(hf, f_o, f_g, r, naive=False):
+    t, u, v, prim = f_o.ray_intersect_preliminary(r, naive=naive)
+    pi = f_g.ray_intersect_preliminary(_ray(hf, r))
+    tg, uvg, pg = pi.t.cpu().numpy(), pi.prim_uv.cpu().numpy(), pi.prim_index.cpu().numpy().view(np.uint32)
+    assert np.array_equal(np.isfinite(t), np.isfinite(tg)), "hit mask differs"
+    assert np.array_equal(prim, pg), f"prim_index differs on {(prim != pg).sum()} rays"
+    hit = np.isfinite(t)
+    assert np.array_equal(t[hit], tg[hit]) or np.allclose(t[hit], tg[hit], rtol=REL, atol=0)
+    assert np.allclose(u, uvg[0], rtol=REL, atol=1e-6) and np.allclose(v, uvg[1], rtol=REL, atol=1e-6)
+    st = f_g.ray_test(_ray(hf, r)).cpu().numpy()
+    assert np.array_equal(st, hit), "ray_test != ray_intersect_preliminary().is_valid()"
+    return hit.mean()
+
+
+@pytest.mark.parametrize("W,H", [(2, 2), (3, 5), (17, 9), (64, 64), (100, 37)])
+@pytest.mark.parametrize("kind", ["rand", "sine", "stairs", "flat"])
+def test_prelim_random_and_structured(hf, oracle, W, H, kind):
+    rng = np.random.default_rng(W * 1000 + H)
+    h = common.heights(kind, W, H, rng)
+    f_o, f_g = _mk(hf, oracle, h)
+    r = np.concatenate([common.random_rays(4000, rng), common.inside_rays(2000, rng)], 1)
+    frac = _check_prelim(hf, f_o, f_g, r, naive=(W * H <= 64 * 64))
+    assert frac > 0.2
+    xs = np.array([f_o.vertex(0, j)[0] for j in range(W)]); ys = np.array([f_o.vertex(i, 0)[1] for i in range(H)])
+    _check_prelim(hf, f_o, f_g, common.structured_rays(xs, ys), naive=(W * H <= 33 * 33))
+
+
+def test_prelim_transformed(hf, oracle):
+    rng = np.random.default_rng(7)
+    tw = common.affine(1)
+    h = common.heights("sine", 129, 65, rng)
+    f_o, f_g = _mk(hf, oracle, h, max_height=0.4, to_world=tw)
+    r = common.to_world_rays(np.concatenate([common.random_rays(20000, rng, 0.4), common.inside_rays(5000, rng, 0.4)], 1), tw)
+    assert _check_prelim(hf, f_o, f_g, r) > 0.3
+    assert np.allclose(f_o.bbox(), f_g.bbox().reshape(-1).numpy(), rtol=1e-6, atol=1e-6)
+
+
+def test_mips_match_oracle(hf, oracle):
+    rng = np.random.default_rng(3)
+    for (W, H) in [(2, 2), (5, 3), (64, 64), (257, 100)]:
+        h = common.heights("rand", W, H, rng)
+        f_o, f_g = _mk(hf, oracle, h, max_height=0.7)
+        assert f_g.num_levels() == max(f_o.num_levels(), 1)
+        for l in range(1, f_o.num_levels() + 1):
+            assert np.array_equal(f_o.mip(l), f_g.mip(l).numpy()), f"mip level {l}"
+
+
+def test_active_mask_and_miss_records(hf, oracle):
+    rng = np.random.default_rng(11)
+    h = common.heights("sine", 33, 33, rng)
+    f_o, f_g = _mk(hf, oracle, h)
+    r = common.random_rays(3000, rng)
+    active = rng.uniform(size=3000) < 0.5
+    t, u, v, prim = f_o.ray_intersect_preliminary(r, active=active)
+    pi = f_g.ray_intersect_preliminary(_ray(hf, r), active=torch.from_numpy(active).cuda())
+    assert np.array_equal(t, pi.t.cpu().numpy()) and np.array_equal(prim, pi.prim_index.cpu().numpy().view(np.uint32))
+    assert np.all(np.isinf(t[~active]))
+    si_o = f_o.compute_surface_interaction(r, t, u, v, prim, oracle.RAY_ALL | oracle.RAY_BOUNDARYTEST, active=active)
+    si_g = pi.compute_surface_interaction(_ray(hf, r), hf.RayFlags.All | hf.RayFlags.BoundaryTest,
+                                          torch.from_numpy(active).cuda())
+    miss = ~np.isfinite(t)
+    assert np.all(np.isinf(si_g.t.cpu().numpy()[miss]))
+    assert np.all(si_g.p.cpu().numpy()[:, miss] == 0) and np.all(si_g.boundary_test.cpu().numpy()[miss] == 1e8)
+    assert np.allclose(si_g.wi.cpu().numpy()[:, miss], -r[3:6, miss])
+    assert np.allclose(si_o["wi"], si_g.wi.cpu().numpy(), rtol=REL, atol=1e-6)
+
+
+def _si_fields(si):
+    return {"t": si.t, "p": si.p, "n": si.n, "uv": si.uv, "sh_n": si.sh_frame.n, "dp_du": si.dp_du,
+            "dp_dv": si.dp_dv, "boundary_test": si.boundary_test, "sh_s": si.sh_frame.s,
+            "sh_t": si.sh_frame.t, "wi": si.wi}
+
+
+@pytest.mark.parametrize("flip", [False, True])
+@pytest.mark.parametrize("mode", ["default", "follow", "detach"])
+def test_surface_interaction_and_adjoint(hf, oracle, mode, flip):
+    rng = np.random.default_rng(5)
+    tw = common.affine(2)
+    h = common.heights("sine", 65, 48, rng)
+    f_o, f_g = _mk(hf, oracle, h, max_height=0.45, to_world=tw, flip=flip)
+    r = common.to_world_rays(common.random_rays(20000, rng, 0.45), tw)
+    flags = oracle.RAY_ALL | oracle.RAY_BOUNDARYTEST | {"default": 0, "follow": oracle.RAY_FOLLOWSHAPE,
+                                                        "detach": oracle.RAY_DETACHSHAPE}[mode]
+    t, u, v, prim = f_o.ray_intersect_preliminary(r)
+    si_o = f_o.compute_surface_interaction(r, t, u, v, prim, flags)
+    ray = _ray(hf, r)
+    pi = f_g.ray_intersect_preliminary(ray)
+    si_g = pi.compute_surface_interaction(ray, flags)
+    fused = f_g.ray_intersect(ray, flags)
+    for name, val in _si_fields(si_g).items():
+        a, b = si_o[name], val.detach().cpu().numpy()
+        assert np.allclose(a, b, rtol=REL, atol=2e-6), f"{mode} SI field {name}: max abs diff {np.abs(a - b).max()}"
+        c = _si_fields(fused)[name].detach().cpu().numpy()
+        assert np.array_equal(b, c, equal_nan=True), f"fused ray_intersect differs from prelim+SI in {name}"
+    # adjoint with a random upstream gradient (seed 12345, cf. src/conftest.py:27-30)
+    grng = np.random.default_rng(12345)
+    g = {nm: grng.normal(size=(c, r.shape[1])).astype(np.float32) for nm, c in oracle.GRAD_FIELDS}
+    gh_o, go_o, gd_o = f_o.adjoint(r, t, u, v, prim, g, flags, ray_grads=True)
+    gblock = torch.from_numpy(np.concatenate([g[nm].reshape(c, -1) for nm, c in oracle.GRAD_FIELDS])).cuda()
+    gh_g, go_g, gd_g = f_g.adjoint(ray, pi, gblock, flags, ray_grads=True)
+    scale = max(np.abs(gh_o).max(), 1e-20)
+    assert np.abs(gh_o - gh_g.cpu().numpy()).max() <= 2e-5 * scale + 1e-12, \
+        f"grad heights: {np.abs(gh_o - gh_g.cpu().numpy()).max()} vs scale {scale}"
+    l2 = np.linalg.norm(gh_o - gh_g.cpu().numpy()) / max(np.linalg.norm(gh_o), 1e-20)
+    assert l2 <= REL or np.linalg.norm(gh_o) == 0
+    assert np.allclose(go_o, go_g.cpu().numpy(), rtol=1e-4, atol=1e-4 * np.abs(go_o).max())
+    assert np.allclose(gd_o, gd_g.cpu().numpy(), rtol=1e-4, atol=1e-4 * np.abs(gd_o).max())
+    if mode == "detach":
+        assert np.all(gh_g.cpu().numpy() == 0)
+
+
+def test_autograd_backward_matches_adjoint(hf, oracle):
+    rng = np.random.default_rng(9)
+    h = common.heights("sine", 40, 40, rng)
+    f_o, f_g = _mk(hf, oracle, h)
+    r = common.random_rays(5000, rng)
+    ray = _ray(hf, r)
+    f_g.heightfield.requires_grad_(True)
+    si = f_g.ray_intersect(ray, hf.RayFlags.All)
+    valid = si.is_valid()
+    loss = si.t[valid].sum() + (si.n[2][valid] * 0.5).sum() + (si.p[0][valid] * si.uv[1][valid]).sum()
+    loss.backward()
+    t, u, v, prim = f_o.ray_intersect_preliminary(r)
+    si_o = f_o.compute_surface_interaction(r, t, u, v, prim)
+    hit = np.isfinite(t)
+    g = {"t": hit.astype(np.float32)[None], "n": np.stack([0 * hit, 0 * hit, 0.5 * hit]).astype(np.float32),
+         "p": np.stack([si_o["uv"][1] * hit, 0 * hit, 0 * hit]).astype(np.float32),
+         "uv": np.stack([0 * hit, si_o["p"][0] * hit]).astype(np.float32)}
+    gh_o = f_o.adjoint(r, t, u, v, prim, g)
+    gh_g = f_g.heightfield.grad.cpu().numpy()
+    assert np.linalg.norm(gh_o - gh_g) <= 1e-5 * np.linalg.norm(gh_o)
+
+
+def test_error_behaviour(hf):
+    with pytest.raises(hf.HfError) as e:
+        hf.Heightfield(heightfield=torch.zeros(1, 5))
+    assert e.value.code == 1
+    f = hf.Heightfield(heightfield=torch.rand(8, 8))
+    ray = hf.Ray3f(torch.tensor([[0.0], [0.0], [2.0]]).cuda(), torch.tensor([[0.0], [0.0], [-1.0]]).cuda())
+    pi = f.ray_intersect_preliminary(ray)
+    with pytest.raises(hf.HfError) as e:   # mesh.cpp:709-711
+        pi.compute_surface_interaction(ray, hf.RayFlags.All | hf.RayFlags.DetachShape | hf.RayFlags.FollowShape)
+    assert e.value.code == 4 and "DetachShape | FollowShape" in str(e.value)
+    with pytest.raises(RuntimeError):
+        hf.Heightfield(heightfield=torch.rand(8, 8), bogus=1)
+    # empty wavefront is legal
+    empty = hf.Ray3f(torch.zeros(3, 0).cuda(), torch.zeros(3, 0).cuda(), torch.zeros(0).cuda())
+    assert f.ray_intersect_preliminary(empty).t.numel() == 0
+    assert f.ray_test(empty).numel() == 0
+    # NaN / inf rays are misses, not hangs
+    bad = hf.Ray3f(torch.tensor([[float("nan")], [0.0], [2.0]]).cuda(), torch.tensor([[0.0], [float("inf")], [-1.0]]).cuda())
+    assert not f.ray_intersect_preliminary(bad).is_valid().any()
