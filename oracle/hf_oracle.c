@@ -302,8 +302,12 @@ static void trace_naive(const hfo_field *f, const float o[3], const float d[3], 
  * the implicit quadtree over 2^top x 2^top cells is skipped when the fat ray
  * segment [0, t_hi] misses its box [min z, max z] read from mip level L.
  */
+/* traversal statistics of the last trace_hier() call on this thread (debug/tuning) */
+static _Thread_local uint32_t g_stat_nodes, g_stat_leaves;
+
 static void trace_hier(const hfo_field *f, const float o[3], const float d[3], float maxt,
                        int any_hit, best_t *b) {
+    g_stat_nodes = 0; g_stat_leaves = 0;
     float oo[3], od[3];
     xform_point(f->to_object, o, oo);
     xform_vec(f->to_object, d, od);
@@ -354,6 +358,7 @@ static void trace_hier(const hfo_field *f, const float o[3], const float d[3], f
 
     int X = 0, Y = 0, L = top;
     for (;;) {
+        ++g_stat_nodes;
         const float S = (float) (1 << L);
         const float bx0 = (float) X * S - m, bx1 = (float) (X + 1) * S + m;
         const float by0 = (float) Y * S - m, by1 = (float) (Y + 1) * S + m;
@@ -390,6 +395,7 @@ static void trace_hier(const hfo_field *f, const float o[3], const float d[3], f
         }
         if (overlap) {
             if (L > 0) { X <<= 1; Y <<= 1; --L; continue; }
+            ++g_stat_leaves;
             if (test_cell(f, ix, iy, oo, od, maxt, b)) {
                 if (any_hit) return;
                 float tb = b->t - tin;
@@ -414,6 +420,11 @@ void hfo_intersect(const hfo_field *f, const float o[3], const float d[3], float
                    float *t, float uv[2], uint32_t *prim) {
     best_t b; trace_hier(f, o, d, maxt, 0, &b); write_result(&b, t, uv, prim);
 }
+void hfo_trace_stats(const hfo_field *f, const float o[3], const float d[3], float maxt,
+                     uint32_t *nodes, uint32_t *leaves) {
+    best_t b; trace_hier(f, o, d, maxt, 0, &b); *nodes = g_stat_nodes; *leaves = g_stat_leaves;
+}
+
 /* ray_test == ray_intersect_preliminary(...).is_valid(), src/render/shape.cpp:430-434 */
 int hfo_ray_test_naive(const hfo_field *f, const float o[3], const float d[3], float maxt) {
     best_t b; trace_naive(f, o, d, maxt, 1, &b); return b.hit;

@@ -110,6 +110,9 @@ void hfo_intersect_naive(const hfo_field *f, const float o[3], const float d[3],
 /* hierarchical min/max-mip traversal; same result as the brute force */
 void hfo_intersect(const hfo_field *f, const float o[3], const float d[3],
                    float maxt, float *t, float uv[2], uint32_t *prim);
+/* number of quadtree nodes visited / cells tested by hfo_intersect for one ray (tuning aid) */
+void hfo_trace_stats(const hfo_field *f, const float o[3], const float d[3], float maxt,
+                     uint32_t *nodes, uint32_t *leaves);
 int  hfo_ray_test_naive(const hfo_field *f, const float o[3], const float d[3], float maxt);
 int  hfo_ray_test(const hfo_field *f, const float o[3], const float d[3], float maxt);
 

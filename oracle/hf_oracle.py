@@ -101,8 +101,11 @@ class OracleField:
             raise ValueError("hfo_create failed (need W,H >= 2)")
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().hfo_destroy(self._h)
+        if getattr(self, "_h", None) and _lib is not None:
+            try:
+                _lib.hfo_destroy(self._h)
+            except Exception:
+                pass
             self._h = None
 
     def set_heights(self, heights):
