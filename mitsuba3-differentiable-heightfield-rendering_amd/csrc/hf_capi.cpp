@@ -4,6 +4,8 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <atomic>
+#include <vector>
 
 #include "hf_launch.h"
 
@@ -14,7 +16,15 @@ struct hf_field {
     size_t mip_nodes;
     int device;
     hipEvent_t built;   // completion of the last hf_set_heights*
+    unsigned long long *d_counters; // ring of work counters, one per in-flight trace launch
+    std::atomic<uint32_t> next_counter;
 };
+
+#define HF_NUM_COUNTERS 1024
+static unsigned long long *next_counter(const hf_field *hf) {
+    hf_field *m = const_cast<hf_field *>(hf);
+    return m->d_counters + (m->next_counter.fetch_add(1) % HF_NUM_COUNTERS) * 16; // 128-byte apart
+}
 
 static thread_local char g_err[512] = "no error";
 
@@ -89,7 +99,7 @@ extern "C" int hf_create(const hf_desc_t *desc, hf_field_t **out) {
         return fail(HF_EDEVICE, "hf_create: device %d not available (%d devices)", desc->device, ndev);
     HF_HIP(hipSetDevice(desc->device));
 
-    hf_field *hf = (hf_field *) calloc(1, sizeof(hf_field));
+    hf_field *hf = (hf_field *) calloc(1, sizeof(hf_field)); // zero-initialised POD + atomic
     if (!hf) return fail(HF_ENOMEM, "hf_create: host allocation failed");
     hf->device = desc->device;
     hf_dev_field &d = hf->dev;
@@ -104,23 +114,23 @@ extern "C" int hf_create(const hf_desc_t *desc, hf_field_t **out) {
     const int cw = d.W - 1, ch = d.H - 1;
     int top = 0;
     while ((1 << top) < cw || (1 << top) < ch) ++top;
-    if (top >= HF_MAX_LEVELS) { free(hf); return fail(HF_EINVAL, "hf_create: grid too large"); }
+    if (top < 1) top = 1;
+    if (top > 16) { free(hf); return fail(HF_EINVAL, "hf_create: grid too large (more than 65536 cells per side)"); }
     d.top = top;
-    d.nlev = top > 1 ? top : 1;
     size_t off = 0;
-    for (int l = 1; l <= d.nlev; ++l) {
-        d.mw[l] = (cw + (1 << l) - 1) >> l;
-        d.mh[l] = (ch + (1 << l) - 1) >> l;
+    for (int l = 1; l <= top; ++l) { // blocked level l: one 4-slot block per level-(l+1) node
         d.moff[l] = (uint32_t) off;
-        off += (size_t) d.mw[l] * d.mh[l];
+        off += 4 * (size_t) hf_level_w(cw, l + 1) * hf_level_w(ch, l + 1);
     }
     hf->mip_nodes = off;
     hipError_t e = hipMalloc((void **) &hf->d_heights, sizeof(float) * (size_t) d.W * d.H);
     if (e == hipSuccess) e = hipMalloc((void **) &hf->d_mip, sizeof(float2) * off);
+    if (e == hipSuccess) e = hipMalloc((void **) &hf->d_counters, sizeof(unsigned long long) * 16 * HF_NUM_COUNTERS);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&hf->built, hipEventDisableTiming);
     if (e != hipSuccess) {
         if (hf->d_heights) (void) hipFree(hf->d_heights);
         if (hf->d_mip) (void) hipFree(hf->d_mip);
+        if (hf->d_counters) (void) hipFree(hf->d_counters);
         free(hf);
         return fail(e == hipErrorOutOfMemory ? HF_ENOMEM : HF_EDEVICE, "hf_create: %s", hipGetErrorString(e));
     }
@@ -142,6 +152,7 @@ extern "C" int hf_destroy(hf_field_t *hf) {
     (void) hipEventDestroy(hf->built);
     (void) hipFree(hf->d_heights);
     (void) hipFree(hf->d_mip);
+    (void) hipFree(hf->d_counters);
     free(hf);
     return HF_OK;
 }
@@ -185,16 +196,26 @@ extern "C" int hf_dims(const hf_field_t *hf, uint32_t *width, uint32_t *height) 
     return HF_OK;
 }
 
-extern "C" int hf_num_levels(const hf_field_t *hf) { return hf ? hf->dev.nlev : 0; }
+extern "C" int hf_num_levels(const hf_field_t *hf) { return hf ? hf->dev.top : 0; }
 
 extern "C" int hf_get_mip(const hf_field_t *hf, int level, float *h_out, uint32_t *w, uint32_t *h) {
-    if (!hf || level < 1 || level > hf->dev.nlev) return fail(HF_EINVAL, "hf_get_mip: bad level %d", level);
-    if (w) *w = (uint32_t) hf->dev.mw[level];
-    if (h) *h = (uint32_t) hf->dev.mh[level];
-    if (h_out) {
+    if (!hf || level < 1 || level > hf->dev.top) return fail(HF_EINVAL, "hf_get_mip: bad level %d", level);
+    const int cw = hf->dev.W - 1, ch = hf->dev.H - 1;
+    const int wl = hf_level_w(cw, level), hl = hf_level_w(ch, level), wl1 = hf_level_w(cw, level + 1),
+              hl1 = hf_level_w(ch, level + 1);
+    if (w) *w = (uint32_t) wl;
+    if (h) *h = (uint32_t) hl;
+    if (h_out) { // un-block into row-major (min,max) pairs
+        std::vector<float> tmp(8 * (size_t) wl1 * hl1);
         HF_HIP(hipEventSynchronize(hf->built));
-        HF_HIP(hipMemcpy(h_out, hf->d_mip + hf->dev.moff[level],
-                         sizeof(float2) * (size_t) hf->dev.mw[level] * hf->dev.mh[level], hipMemcpyDeviceToHost));
+        HF_HIP(hipMemcpy(tmp.data(), hf->d_mip + hf->dev.moff[level], sizeof(float) * tmp.size(),
+                         hipMemcpyDeviceToHost));
+        for (int iy = 0; iy < hl; ++iy)
+            for (int ix = 0; ix < wl; ++ix) {
+                const size_t slot = 4 * ((size_t) (iy >> 1) * wl1 + (ix >> 1)) + 2 * (iy & 1) + (ix & 1);
+                h_out[2 * ((size_t) iy * wl + ix) + 0] = tmp[2 * slot + 0];
+                h_out[2 * ((size_t) iy * wl + ix) + 1] = tmp[2 * slot + 1];
+            }
     }
     return HF_OK;
 }
@@ -204,7 +225,7 @@ extern "C" int hf_bbox(hf_field_t *hf, float out[6]) {
     if (!hf || !out) return fail(HF_EINVAL, "hf_bbox: NULL argument");
     float zr[2];
     HF_HIP(hipEventSynchronize(hf->built));
-    HF_HIP(hipMemcpy(zr, hf->d_mip + hf->dev.moff[hf->dev.nlev], sizeof(zr), hipMemcpyDeviceToHost));
+    HF_HIP(hipMemcpy(zr, hf->d_mip + hf->dev.moff[hf->dev.top], sizeof(zr), hipMemcpyDeviceToHost));
     const hf_dev_field &d = hf->dev;
     const float lo[3] = { fmaf(0.f, d.sx, -1.f), fmaf(0.f, d.sy, -1.f), zr[0] };
     const float hi[3] = { fmaf((float) (d.W - 1), d.sx, -1.f), fmaf((float) (d.H - 1), d.sy, -1.f), zr[1] };
@@ -251,7 +272,7 @@ extern "C" int hf_ray_intersect_preliminary(const hf_field_t *hf, size_t n, cons
     int rc = check_rays("hf_ray_intersect_preliminary", hf, n, rays);
     if (rc) return rc;
     if (!out || (n && !out->t)) return fail(HF_EINVAL, "hf_ray_intersect_preliminary: NULL output");
-    hf_launch_trace(0, hf->dev, n, rays, active, out, nullptr, nullptr, 0, (hipStream_t) stream);
+    hf_launch_trace(0, hf->dev, n, rays, active, out, nullptr, nullptr, 0, next_counter(hf), (hipStream_t) stream);
     HF_HIP(hipGetLastError());
     return HF_OK;
 }
@@ -261,7 +282,7 @@ extern "C" int hf_ray_test(const hf_field_t *hf, size_t n, const hf_rays_t *rays
     int rc = check_rays("hf_ray_test", hf, n, rays);
     if (rc) return rc;
     if (n && !out_hit) return fail(HF_EINVAL, "hf_ray_test: NULL output");
-    hf_launch_trace(1, hf->dev, n, rays, active, nullptr, out_hit, nullptr, 0, (hipStream_t) stream);
+    hf_launch_trace(1, hf->dev, n, rays, active, nullptr, out_hit, nullptr, 0, next_counter(hf), (hipStream_t) stream);
     HF_HIP(hipGetLastError());
     return HF_OK;
 }
@@ -286,7 +307,8 @@ extern "C" int hf_ray_intersect(const hf_field_t *hf, size_t n, const hf_rays_t 
     if (rc) return rc;
     if ((rc = check_flags("hf_ray_intersect", ray_flags))) return rc;
     if (!out_si) return fail(HF_EINVAL, "hf_ray_intersect: NULL output");
-    hf_launch_trace(2, hf->dev, n, rays, active, out_pi, nullptr, out_si, ray_flags, (hipStream_t) stream);
+    hf_launch_trace(2, hf->dev, n, rays, active, out_pi, nullptr, out_si, ray_flags, next_counter(hf),
+                    (hipStream_t) stream);
     HF_HIP(hipGetLastError());
     return HF_OK;
 }

@@ -62,19 +62,28 @@ __device__ __forceinline__ v3 xform_vec(const float *m, v3 v) {
     return r;
 }
 
-// Device view of one heightfield: heights + concatenated min/max mip levels.
+// Device view of one heightfield: heights + min/max mip pyramid.
+//
+// Quadtree over 2^top x 2^top cells (top >= 1; cells beyond the grid do not exist).
+// A node of level l covers 2^l x 2^l cells; level l has w_l x h_l existing nodes,
+// w_l = ceil((W-1)/2^l).  Level l (1..top) is stored BLOCKED: the four children
+// (2ix+jx, 2iy+jy) of the level-(l+1) node (ix,iy) are contiguous,
+//     mip[moff[l] + 4*(iy*w_{l+1} + ix) + 2*jy + jx] = (min z, max z),
+// so one parent visit fetches its 4 child boxes with two 16-byte loads.  Slots of
+// non-existent nodes hold (+inf, -inf) and fail every overlap test.
 struct hf_dev_field {
     const float *h;    // W*H heights, row-major
-    const float2 *mip; // levels 1..nlev back to back; level l at mip + moff[l], mw[l] x mh[l]
+    const float2 *mip; // levels 1..top back to back
     uint32_t moff[HF_MAX_LEVELS + 1];
-    int32_t mw[HF_MAX_LEVELS + 1], mh[HF_MAX_LEVELS + 1];
     int32_t W, H;
-    int32_t top;  // ceil(log2(max(W-1,H-1))): quadtree depth over the cells (may be 0)
-    int32_t nlev; // max(top,1): number of stored levels; mip[moff[nlev]] is the global (min,max)
+    int32_t top;  // max(ceil(log2(max(W-1,H-1))), 1); mip[moff[top]] is the global (min,max)
     float s, sx, sy, iu, iv;
     int32_t flip;
     float to_world[12], to_object[12];
 };
+
+// number of existing nodes per row / column at level l
+__host__ __device__ __forceinline__ int hf_level_w(int cells, int l) { return (cells + (1 << l) - 1) >> l; }
 
 struct hf_hit {
     float t, u, v;

@@ -8,74 +8,84 @@
 //   hf_si_kernel                                   compute_surface_interaction (row a4)
 //   hf_adjoint_kernel                              reverse mode of a4, atomic scatter (row a5)
 //
-// Traversal = scan of the cells along a Morton curve mirrored so the ray direction
-// is non-negative on both axes ("order space"), with whole quadtree nodes (X,Y,L)
-// skipped when the *fat* ray segment [0,t_hi] misses the node's box
-// [x..x+2^L] x [y..y+2^L] x [min z, max z] (mip level L).  The visited set is a
-// conservative superset of the cells the ray can hit; the per-triangle test and
-// the tie rule are order independent, so the result equals the brute force's.
+// Traversal = depth-first walk of the implicit quadtree over the cells, children in
+// front-to-back order (the grid is mirrored so the ray direction is non-negative on
+// both axes: "order space").  One visit of an inner node fetches the (min z, max z)
+// boxes of its 4 children (blocked mip layout) and keeps those the *fat* ray segment
+// [0,t_hi] overlaps; a level-1 node fetches its 3x3 heights and tests the triangles
+// of the overlapped cells.  Pending children live in a 4-bit-per-level mask stack in
+// one 64-bit register.  The visited set is a conservative superset of the cells the
+// ray can hit; the per-triangle test and the tie rule are order independent, so the
+// result equals the brute force's.
 #include "hf_device.h"
 #include "hf_launch.h"
 
 #define HF_BLOCK 256
-#define HF_LDS_LEVELS 6           // top mip levels staged in LDS: <= 1+4+16+64+256+1024 nodes
-#define HF_LDS_NODES 1365
+#define HF_LDS_LEVELS 6           // top mip levels staged in LDS (4+4+16+64+256+1024 entries for a square grid)
+#define HF_LDS_NODES 1368
 
 // ---------------------------------------------------------------------------------
-// min/max mip pyramid
+// min/max mip pyramid (blocked layout, see hf_dev_field)
 // ---------------------------------------------------------------------------------
+// one thread per slot of level 1: slot = 4*block + k, block = (by*w2 + bx), node = (2bx+(k&1), 2by+(k>>1))
 __global__ __launch_bounds__(HF_BLOCK) void hf_mip_level1_kernel(const float *__restrict__ h, int W, int H, float s,
-                                                                float2 *__restrict__ out, int mw, int mh) {
-    const int idx = blockIdx.x * HF_BLOCK + threadIdx.x;
-    if (idx >= mw * mh) return;
-    const int iy = idx / mw, ix = idx - iy * mw;
+                                                                float2 *__restrict__ out, int w1, int h1, int w2,
+                                                                int nslots) {
+    const int slot = blockIdx.x * HF_BLOCK + threadIdx.x;
+    if (slot >= nslots) return;
+    const int k = slot & 3, b = slot >> 2;
+    const int by = b / w2, bx = b - by * w2;
+    const int ix = 2 * bx + (k & 1), iy = 2 * by + (k >> 1);
     float mn = __builtin_inff(), mx = -__builtin_inff();
+    if (ix < w1 && iy < h1) {
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        const int i = 2 * iy + a;
-        if (i >= H) break;
+        for (int a = 0; a < 3; ++a) {
+            const int i = 2 * iy + a;
+            if (i >= H) break;
 #pragma unroll
-        for (int b = 0; b < 3; ++b) {
-            const int j = 2 * ix + b;
-            if (j < W) {
-                const float z = h[(size_t) i * W + j] * s;
-                mn = fminf(mn, z); mx = fmaxf(mx, z);
+            for (int c = 0; c < 3; ++c) {
+                const int j = 2 * ix + c;
+                if (j < W) {
+                    const float z = h[(size_t) i * W + j] * s;
+                    mn = fminf(mn, z); mx = fmaxf(mx, z);
+                }
             }
         }
     }
-    out[idx] = make_float2(mn, mx);
+    out[slot] = make_float2(mn, mx);
 }
 
-__global__ __launch_bounds__(HF_BLOCK) void hf_mip_reduce_kernel(const float2 *__restrict__ in, int pw, int ph,
-                                                                float2 *__restrict__ out, int mw, int mh) {
-    const int idx = blockIdx.x * HF_BLOCK + threadIdx.x;
-    if (idx >= mw * mh) return;
-    const int iy = idx / mw, ix = idx - iy * mw;
+// level l >= 2 from level l-1: node (ix,iy) reduces block (iy*w_l + ix) of the level below
+__global__ __launch_bounds__(HF_BLOCK) void hf_mip_reduce_kernel(const float2 *__restrict__ in, float2 *__restrict__ out,
+                                                                int wl, int hl, int wl1, int nslots) {
+    const int slot = blockIdx.x * HF_BLOCK + threadIdx.x;
+    if (slot >= nslots) return;
+    const int k = slot & 3, b = slot >> 2;
+    const int by = b / wl1, bx = b - by * wl1;
+    const int ix = 2 * bx + (k & 1), iy = 2 * by + (k >> 1);
     float mn = __builtin_inff(), mx = -__builtin_inff();
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const int jy = 2 * iy + a, jx = 2 * ix + b;
-            if (jy < ph && jx < pw) {
-                const float2 c = in[(size_t) jy * pw + jx];
-                mn = fminf(mn, c.x); mx = fmaxf(mx, c.y);
-            }
-        }
-    out[idx] = make_float2(mn, mx);
+    if (ix < wl && iy < hl) {
+        const float4 *c = (const float4 *) (in + 4 * ((size_t) iy * wl + ix));
+        const float4 a = c[0], d = c[1];
+        mn = fminf(fminf(a.x, a.z), fminf(d.x, d.z));
+        mx = fmaxf(fmaxf(a.y, a.w), fmaxf(d.y, d.w));
+    }
+    out[slot] = make_float2(mn, mx);
 }
 
 void hf_launch_build_mips(const hf_dev_field &f, float2 *mip, hipStream_t stream) {
-    for (int l = 1; l <= f.nlev; ++l) {
-        const int n = f.mw[l] * f.mh[l];
-        const int grid = (n + HF_BLOCK - 1) / HF_BLOCK;
+    const int cw = f.W - 1, ch = f.H - 1;
+    for (int l = 1; l <= f.top; ++l) {
+        const int wl = hf_level_w(cw, l), hl = hf_level_w(ch, l);
+        const int wl1 = hf_level_w(cw, l + 1), hl1 = hf_level_w(ch, l + 1);
+        const int nslots = 4 * wl1 * hl1;
+        const int grid = (nslots + HF_BLOCK - 1) / HF_BLOCK;
         if (l == 1)
             hipLaunchKernelGGL(hf_mip_level1_kernel, dim3(grid), dim3(HF_BLOCK), 0, stream, f.h, f.W, f.H, f.s,
-                               mip + f.moff[1], f.mw[1], f.mh[1]);
+                               mip + f.moff[1], wl, hl, wl1, nslots);
         else
             hipLaunchKernelGGL(hf_mip_reduce_kernel, dim3(grid), dim3(HF_BLOCK), 0, stream,
-                               (const float2 *) (mip + f.moff[l - 1]), f.mw[l - 1], f.mh[l - 1], mip + f.moff[l],
-                               f.mw[l], f.mh[l]);
+                               (const float2 *) (mip + f.moff[l - 1]), mip + f.moff[l], wl, hl, wl1, nslots);
     }
 }
 
@@ -84,31 +94,77 @@ void hf_launch_build_mips(const hf_dev_field &f, float2 *mip, hipStream_t stream
 // ---------------------------------------------------------------------------------
 struct hf_lds_mips {
     float2 node[HF_LDS_NODES];
-    uint32_t goff[HF_MAX_LEVELS + 1]; // global offset of level l
+    uint32_t goff[HF_MAX_LEVELS + 1]; // global offset (float2 units) of level l
     uint32_t loff[HF_MAX_LEVELS + 1]; // LDS offset of level l (valid for l >= lo)
     int lo;                           // lowest staged level
 };
 
 __device__ __forceinline__ void stage_mips(const hf_dev_field &f, hf_lds_mips &s) {
     const int tid = threadIdx.x;
-    int lo = f.nlev - (HF_LDS_LEVELS - 1);
-    if (lo < 1) lo = 1;
+    const int cw = f.W - 1, ch = f.H - 1;
+    // stage levels top, top-1, ... while they fit
+    int lo = f.top + 1;
+    uint32_t acc = 0;
+    for (int l = f.top; l >= 1 && l > f.top - HF_LDS_LEVELS; --l) {
+        const uint32_t cnt = 4u * (uint32_t) (hf_level_w(cw, l + 1) * hf_level_w(ch, l + 1));
+        if (acc + cnt > HF_LDS_NODES) break;
+        for (uint32_t k = tid; k < cnt; k += HF_BLOCK) s.node[acc + k] = f.mip[f.moff[l] + k];
+        if (tid == 0) s.loff[l] = acc;
+        acc += cnt;
+        lo = l;
+    }
     if (tid == 0) {
-        uint32_t acc = 0;
-        for (int l = f.nlev; l >= 1; --l) {
-            s.goff[l] = f.moff[l];
-            s.loff[l] = acc;
-            if (l >= lo) acc += (uint32_t) (f.mw[l] * f.mh[l]);
-        }
+        for (int l = 1; l <= f.top; ++l) s.goff[l] = f.moff[l];
         s.lo = lo;
     }
-    uint32_t acc = 0;
-    for (int l = f.nlev; l >= lo; --l) {
-        const int cnt = f.mw[l] * f.mh[l];
-        for (int k = tid; k < cnt; k += HF_BLOCK) s.node[acc + k] = f.mip[f.moff[l] + k];
-        acc += (uint32_t) cnt;
-    }
     __syncthreads();
+}
+
+// per-ray traversal constants (order space, cell units, re-based at t = tin)
+struct hf_trav {
+    float gxm, gxp, gym, gyp; // origin x,y  +/- the xy margin m
+    float gz, dz, idx, idy, mz;
+    uint32_t fxm, fym;        // mirror masks ((1<<top)-1 or 0)
+    bool fx, fy;
+};
+
+// children of an inner node as 4 (min,max) boxes in ACTUAL child order j = 2*jy + jx
+struct hf_quad {
+    float lo[4], hi[4];
+};
+
+// overlap mask (order-space child numbering k = 2*ky + kx) of the fat ray segment [0,thi]
+// with the four child boxes of the node whose order-space origin is (fX,fY), child size S.
+__device__ __forceinline__ uint32_t child_mask(const hf_trav &r, float fX, float fY, float S, const hf_quad &q,
+                                               float thi, float tent[4]) {
+    // t-intervals of the near / far half along x and y (direction >= 0 in order space);
+    // fmaxf/fminf below drop the NaN of 0*inf (origin exactly on a plane of an axis-parallel ray)
+    const float xn0 = (fX - r.gxm) * r.idx, xn1 = (fX + S - r.gxp) * r.idx;
+    const float xf0 = (fX + S - r.gxm) * r.idx, xf1 = (fX + (S + S) - r.gxp) * r.idx;
+    const float yn0 = (fY - r.gym) * r.idy, yn1 = (fY + S - r.gyp) * r.idy;
+    const float yf0 = (fY + S - r.gym) * r.idy, yf1 = (fY + (S + S) - r.gyp) * r.idy;
+    // actual child column 0 is the near half unless the axis is mirrored
+    const float x0lo = r.fx ? xf0 : xn0, x0hi = r.fx ? xf1 : xn1, x1lo = r.fx ? xn0 : xf0, x1hi = r.fx ? xn1 : xf1;
+    const float y0lo = r.fy ? yf0 : yn0, y0hi = r.fy ? yf1 : yn1, y1lo = r.fy ? yn0 : yf0, y1hi = r.fy ? yn1 : yf1;
+    uint32_t m = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float xlo = (j & 1) ? x1lo : x0lo, xhi = (j & 1) ? x1hi : x0hi;
+        const float ylo = (j & 2) ? y1lo : y0lo, yhi = (j & 2) ? y1hi : y0hi;
+        const float t0 = fmaxf(fmaxf(xlo, ylo), 0.f), t1 = fminf(fminf(xhi, yhi), thi);
+        const float za = __builtin_fmaf(t0, r.dz, r.gz), zb = __builtin_fmaf(t1, r.dz, r.gz);
+        const bool ok = (t0 <= t1) & (fminf(za, zb) - r.mz <= q.hi[j]) & (fmaxf(za, zb) + r.mz >= q.lo[j]);
+        tent[j] = t0;
+        m |= ok ? (1u << j) : 0u;
+    }
+    return m;
+}
+
+// actual-child mask -> order-space child mask (bit k = bit (k ^ flip))
+__device__ __forceinline__ uint32_t to_order(uint32_t m, bool fx, bool fy) {
+    if (fx) m = ((m & 5u) << 1) | ((m >> 1) & 5u);
+    if (fy) m = ((m & 3u) << 2) | ((m >> 2) & 3u);
+    return m;
 }
 
 template <bool ANY>
@@ -116,14 +172,14 @@ __device__ __forceinline__ void trace_ray(const hf_dev_field &f, const hf_lds_mi
                                           hf_hit &best) {
     best.hit = false; best.t = __builtin_inff(); best.u = 0.f; best.v = 0.f; best.prim = 0u;
     const v3 oo = xform_point(f.to_object, o), od = xform_vec(f.to_object, d);
-    // non-finite input or NaN/negative maxt: miss (also bounds the scan below)
+    // non-finite input or NaN/negative maxt: miss (also bounds the walk below)
     {
         const float chk = (oo.x + oo.y + oo.z) + (od.x + od.y + od.z);
         if (!(__builtin_fabsf(chk) < __builtin_inff()) || !(maxt >= 0.f)) return;
     }
     const int cw = f.W - 1, ch = f.H - 1, top = f.top;
     const float hx = 0.5f * (float) cw, hy = 0.5f * (float) ch;
-    const float2 zr = s.node[0]; // root of the pyramid = global (min z, max z)
+    const float2 zr = s.node[0]; // first staged entry = root of the pyramid = global (min z, max z)
     const float zspan = fmaxf(zr.y - zr.x, fmaxf(__builtin_fabsf(zr.x), __builtin_fabsf(zr.y)));
     const float mz0 = 1e-5f * zspan + 1e-30f;
 
@@ -139,8 +195,8 @@ __device__ __forceinline__ void trace_ray(const hf_dev_field &f, const hf_lds_mi
             if (dc[k] == 0.f) {
                 outside |= (oc[k] < lo[k]) | (oc[k] > hi[k]);
             } else {
-                const float r = 1.0f / dc[k];
-                const float t1 = (lo[k] - oc[k]) * r, t2 = (hi[k] - oc[k]) * r;
+                const float rr = 1.0f / dc[k];
+                const float t1 = (lo[k] - oc[k]) * rr, t2 = (hi[k] - oc[k]) * rr;
                 tin = fmaxf(tin, fminf(t1, t2));
                 tout = fminf(tout, fmaxf(t1, t2));
             }
@@ -152,87 +208,118 @@ __device__ __forceinline__ void trace_ray(const hf_dev_field &f, const hf_lds_mi
     }
 
     // traversal ray in cell units, re-based at t = tin, mirrored into order space
-    const bool fx = od.x < 0.f, fy = od.y < 0.f;
+    hf_trav r;
+    r.fx = od.x < 0.f; r.fy = od.y < 0.f;
     const float Wp = (float) (1 << top);
     float gx = (__builtin_fmaf(tin, od.x, oo.x) + 1.f) * hx, gy = (__builtin_fmaf(tin, od.y, oo.y) + 1.f) * hy;
-    const float gz = __builtin_fmaf(tin, od.z, oo.z);
+    r.gz = __builtin_fmaf(tin, od.z, oo.z);
     float dx = od.x * hx, dy = od.y * hy;
-    const float dz = od.z;
-    if (fx) { gx = Wp - gx; dx = -dx; }
-    if (fy) { gy = Wp - gy; dy = -dy; }
-    const float idx = 1.0f / dx, idy = 1.0f / dy; // +inf for axis-parallel rays
+    r.dz = od.z;
+    if (r.fx) { gx = Wp - gx; dx = -dx; }
+    if (r.fy) { gy = Wp - gy; dy = -dy; }
+    r.idx = 1.0f / dx; r.idy = 1.0f / dy; // +inf for axis-parallel rays
     const float reach = __builtin_fabsf(oo.x) + __builtin_fabsf(oo.y) +
                         tin * (__builtin_fabsf(od.x) + __builtin_fabsf(od.y)) + 2.f;
     const float m = 0.015625f + 4.8e-7f * reach * fmaxf(hx, hy);
-    const float mz = mz0 + 4.8e-7f * (__builtin_fabsf(oo.z) + tin * __builtin_fabsf(od.z) + zspan);
-    const float gxm = gx + m, gxp = gx - m, gym = gy + m, gyp = gy - m;
+    r.mz = mz0 + 4.8e-7f * (__builtin_fabsf(oo.z) + tin * __builtin_fabsf(od.z) + zspan);
+    r.gxm = gx + m; r.gxp = gx - m; r.gym = gy + m; r.gyp = gy - m;
     float thi = tout - tin;
     thi = thi + thi * 1e-6f + 1e-30f;
-    const uint32_t fxm = fx ? ((1u << top) - 1u) : 0u, fym = fy ? ((1u << top) - 1u) : 0u;
+    r.fxm = r.fx ? ((1u << top) - 1u) : 0u;
+    r.fym = r.fy ? ((1u << top) - 1u) : 0u;
 
-    uint32_t X = 0, Y = 0;
+    // walk: (X,Y,L) = current inner node in order space, `cur` = its children still to visit
+    // (bit k = order-space child 2*ky+kx), `stk` = the same masks of the ancestors, 4 bits each.
+    uint32_t X = 0, Y = 0, cur = 0;
     int L = top;
-    bool done = false;
+    uint64_t stk = 0;
+    bool done = false, have = (top == 1); // top == 1: the root itself is a leaf parent
+    uint32_t lX = 0, lY = 0;
+    bool fresh = (top > 1);               // root needs expanding
     for (;;) {
-        // ---- phase 1: walk quadtree nodes until this lane holds a candidate cell ----
-        bool leaf = false;
-        int lx = 0, ly = 0;
-        float z00 = 0.f, z10 = 0.f, z01 = 0.f, z11 = 0.f;
-        while (!done && !leaf) {
-            const float S = (float) (1u << L);
-            const float fX = (float) X * S, fY = (float) Y * S;
-            // order-space direction is >= 0: entry = low faces, exit = high faces.
-            // fmaxf/fminf drop the NaN of 0 * inf (origin exactly on a face plane).
-            const float t0 = fmaxf(fmaxf((fX - gxm) * idx, (fY - gym) * idy), 0.f);
-            const float t1 = fminf(fminf((fX + S - gxp) * idx, (fY + S - gyp) * idy), thi);
-            bool overlap = false;
-            const int ix = (int) (X ^ (fxm >> L)), iy = (int) (Y ^ (fym >> L));
-            if (t0 <= t1) {
-                float zlo = 0.f, zhi = 0.f;
-                bool inside;
-                if (L == 0) {
-                    inside = (ix < cw) & (iy < ch);
-                    if (inside) {
-                        const float *r0 = f.h + (size_t) iy * f.W + ix;
-                        z00 = r0[0] * f.s; z10 = r0[1] * f.s;
-                        z01 = r0[f.W] * f.s; z11 = r0[f.W + 1] * f.s;
-                        zlo = fminf(fminf(z00, z10), fminf(z01, z11));
-                        zhi = fmaxf(fmaxf(z00, z10), fmaxf(z01, z11));
-                    }
+        // ---- phase 1: inner nodes, until this lane holds a level-1 node (2x2 cells) to test ----
+        while (!done && !have) {
+            if (fresh) { // expand node (X,Y,L), L >= 2: fetch its 4 child boxes, build the pending mask
+                fresh = false;
+                const uint32_t ix = X ^ (r.fxm >> L), iy = Y ^ (r.fym >> L);
+                const uint32_t blk = 4u * (iy * (uint32_t) hf_level_w(cw, L) + ix);
+                float4 a, b;
+                if (L - 1 >= s.lo) {
+                    const float4 *c = (const float4 *) (s.node + s.loff[L - 1] + blk);
+                    a = c[0]; b = c[1];
                 } else {
-                    const int w = (cw + (1 << L) - 1) >> L, hh = (ch + (1 << L) - 1) >> L;
-                    inside = (ix < w) & (iy < hh);
-                    if (inside) {
-                        float2 c;
-                        if (L >= s.lo) c = s.node[s.loff[L] + (uint32_t) (iy * w + ix)];
-                        else           c = f.mip[s.goff[L] + (uint32_t) iy * (uint32_t) w + (uint32_t) ix];
-                        zlo = c.x; zhi = c.y;
-                    }
+                    const float4 *c = (const float4 *) (f.mip + s.goff[L - 1] + blk);
+                    a = c[0]; b = c[1];
                 }
-                if (inside) {
-                    const float za = __builtin_fmaf(t0, dz, gz), zb = __builtin_fmaf(t1, dz, gz);
-                    overlap = (fminf(za, zb) - mz <= zhi) & (fmaxf(za, zb) + mz >= zlo);
-                }
-            }
-            if (overlap && L > 0) { // descend to the first child in order space
-                X <<= 1; Y <<= 1; --L;
+                hf_quad q;
+                q.lo[0] = a.x; q.hi[0] = a.y; q.lo[1] = a.z; q.hi[1] = a.w;
+                q.lo[2] = b.x; q.hi[2] = b.y; q.lo[3] = b.z; q.hi[3] = b.w;
+                const float S = (float) (1u << (L - 1));
+                float tent[4];
+                cur = to_order(child_mask(r, (float) X * (S + S), (float) Y * (S + S), S, q, thi, tent), r.fx, r.fy);
                 continue;
             }
-            if (overlap) { leaf = true; lx = ix; ly = iy; }
-            // advance: climb while this is the last (k=3) child, then step to the next sibling
-            const int c = __builtin_ctz(~(X & Y));
-            X >>= c; Y >>= c; L += c;
-            if (L >= top) done = true;
-            else if ((X & 1u) == 0u) X |= 1u;
-            else { X &= ~1u; Y |= 1u; }
+            if (cur == 0u) { // node exhausted: pop
+                if (L == top) { done = true; continue; }
+                cur = (uint32_t) stk & 15u; stk >>= 4;
+                X >>= 1; Y >>= 1; ++L;
+                continue;
+            }
+            const uint32_t k = (uint32_t) __builtin_ctz(cur);
+            cur &= cur - 1u;
+            const uint32_t cx = 2u * X + (k & 1u), cy = 2u * Y + (k >> 1);
+            // the mask may predate a hit: re-check the child's entry against the current t_hi
+            const float S = (float) (1u << (L - 1));
+            const float te = fmaxf(((float) cx * S - r.gxm) * r.idx, ((float) cy * S - r.gym) * r.idy);
+            if (te > thi) continue;
+            if (L == 2) { have = true; lX = cx; lY = cy; continue; }
+            stk = (stk << 4) | (uint64_t) cur;
+            X = cx; Y = cy; --L; fresh = true;
         }
-        if (!leaf) break;
-        // ---- phase 2: the two triangles of the candidate cell (spec arithmetic) ----
-        if (test_cell(f, lx, ly, z00, z10, z01, z11, oo, od, maxt, best)) {
-            if (ANY) break;
-            float tb = best.t - tin;
-            tb = tb + __builtin_fabsf(tb) * 1e-6f + 1e-30f;
-            thi = fminf(thi, tb);
+        if (!have) break;
+        have = false;
+        // ---- phase 2: the 2x2 cells of level-1 node (lX,lY): 3x3 heights, then triangles ----
+        {
+            const uint32_t ix = lX ^ (r.fxm >> 1), iy = lY ^ (r.fym >> 1);
+            const int c0 = (int) (2u * ix), r0 = (int) (2u * iy);
+            const int c1 = min(c0 + 1, f.W - 1), c2 = min(c0 + 2, f.W - 1);
+            const int r1 = min(r0 + 1, f.H - 1), r2 = min(r0 + 2, f.H - 1);
+            const float *p0 = f.h + (size_t) r0 * f.W, *p1 = f.h + (size_t) r1 * f.W, *p2 = f.h + (size_t) r2 * f.W;
+            const float z00 = p0[c0] * f.s, z01 = p0[c1] * f.s, z02 = p0[c2] * f.s;
+            const float z10 = p1[c0] * f.s, z11 = p1[c1] * f.s, z12 = p1[c2] * f.s;
+            const float z20 = p2[c0] * f.s, z21 = p2[c1] * f.s, z22 = p2[c2] * f.s;
+            const bool vx1 = c0 + 1 < cw, vy1 = r0 + 1 < ch; // cells (c0,r0) always exist
+            const float inf = __builtin_inff();
+            hf_quad q;
+            q.lo[0] = fminf(fminf(z00, z01), fminf(z10, z11)); q.hi[0] = fmaxf(fmaxf(z00, z01), fmaxf(z10, z11));
+            q.lo[1] = vx1 ? fminf(fminf(z01, z02), fminf(z11, z12)) : inf;
+            q.hi[1] = vx1 ? fmaxf(fmaxf(z01, z02), fmaxf(z11, z12)) : -inf;
+            q.lo[2] = vy1 ? fminf(fminf(z10, z11), fminf(z20, z21)) : inf;
+            q.hi[2] = vy1 ? fmaxf(fmaxf(z10, z11), fmaxf(z20, z21)) : -inf;
+            q.lo[3] = (vx1 & vy1) ? fminf(fminf(z11, z12), fminf(z21, z22)) : inf;
+            q.hi[3] = (vx1 & vy1) ? fmaxf(fmaxf(z11, z12), fmaxf(z21, z22)) : -inf;
+            float tent[4];
+            const uint32_t cm = child_mask(r, (float) lX * 2.f, (float) lY * 2.f, 1.f, q, thi, tent);
+            bool hit_any = false;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if ((cm >> j) & 1u) {
+                    if (tent[j] <= thi) {
+                        const float a = (j == 0) ? z00 : (j == 1) ? z01 : (j == 2) ? z10 : z11;
+                        const float b = (j == 0) ? z01 : (j == 1) ? z02 : (j == 2) ? z11 : z12;
+                        const float c = (j == 0) ? z10 : (j == 1) ? z11 : (j == 2) ? z20 : z21;
+                        const float e = (j == 0) ? z11 : (j == 1) ? z12 : (j == 2) ? z21 : z22;
+                        if (test_cell(f, c0 + (j & 1), r0 + (j >> 1), a, b, c, e, oo, od, maxt, best)) {
+                            hit_any = true;
+                            float tb = best.t - tin;
+                            tb = tb + __builtin_fabsf(tb) * 1e-6f + 1e-30f;
+                            thi = fminf(thi, tb);
+                        }
+                    }
+                }
+            }
+            if (ANY && hit_any) break;
+            if (top == 1) break; // single leaf parent: nothing else to visit
         }
     }
 }
@@ -281,34 +368,49 @@ __device__ __forceinline__ void miss_si(hf_si_rec &si, v3 d, uint32_t flags) {
     si.wi = neg3(d);
 }
 
+#define HF_GRAB 128 // rays a wave takes from the work counter per fetch
+
+// Persistent waves: every wave pulls HF_GRAB consecutive rays at a time from a global
+// counter (zeroed on the stream before the launch), so expensive image regions are
+// spread over all CUs whatever their position in the wavefront.
 template <int MODE>
 __global__ __launch_bounds__(HF_BLOCK) void hf_trace_kernel(hf_dev_field f, size_t n, hf_rays_dev rays,
                                                             const uint8_t *__restrict__ active, hf_pi_dev pi,
                                                             uint8_t *__restrict__ hit_out, hf_si_dev sio,
-                                                            uint32_t flags) {
+                                                            uint32_t flags, unsigned long long *counter) {
     __shared__ hf_lds_mips s;
     stage_mips(f, s);
-    const size_t stride = (size_t) gridDim.x * HF_BLOCK;
-    for (size_t i = (size_t) blockIdx.x * HF_BLOCK + threadIdx.x; i < n; i += stride) {
-        const v3 o = mk3(rays.o[0][i], rays.o[1][i], rays.o[2][i]);
-        const v3 d = mk3(rays.d[0][i], rays.d[1][i], rays.d[2][i]);
-        const float maxt = rays.maxt[i];
-        hf_hit best;
-        best.hit = false; best.t = __builtin_inff(); best.u = 0.f; best.v = 0.f; best.prim = 0u;
-        const bool act = active ? (active[i] != 0) : true;
-        if (act) trace_ray<MODE == 1>(f, s, o, d, maxt, best);
-        if (MODE == 1) {
-            hit_out[i] = best.hit ? 1 : 0;
-        } else {
-            if (pi.t) pi.t[i] = best.hit ? best.t : __builtin_inff();
-            if (pi.u) pi.u[i] = best.hit ? best.u : 0.f;
-            if (pi.v) pi.v[i] = best.hit ? best.v : 0.f;
-            if (pi.prim) pi.prim[i] = best.hit ? best.prim : 0u;
-            if (MODE == 2) {
-                hf_si_rec si;
-                if (best.hit) compute_si(f, o, d, best.t, best.u, best.v, best.prim, flags, si);
-                else          miss_si(si, d, flags);
-                store_si(sio, i, si, flags);
+    const unsigned lane = threadIdx.x & 63u;
+    for (;;) {
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(counter, (unsigned long long) HF_GRAB);
+        base = ((unsigned long long) (uint32_t) __builtin_amdgcn_readfirstlane((int) (base >> 32)) << 32) |
+               (unsigned long long) (uint32_t) __builtin_amdgcn_readfirstlane((int) (base & 0xffffffffull));
+        if (base >= n) break;
+#pragma unroll 1
+        for (unsigned sub = 0; sub < HF_GRAB; sub += 64) {
+            const size_t i = base + sub + lane;
+            if (i >= n) break;
+            const v3 o = mk3(rays.o[0][i], rays.o[1][i], rays.o[2][i]);
+            const v3 d = mk3(rays.d[0][i], rays.d[1][i], rays.d[2][i]);
+            const float maxt = rays.maxt[i];
+            hf_hit best;
+            best.hit = false; best.t = __builtin_inff(); best.u = 0.f; best.v = 0.f; best.prim = 0u;
+            const bool act = active ? (active[i] != 0) : true;
+            if (act) trace_ray<MODE == 1>(f, s, o, d, maxt, best);
+            if (MODE == 1) {
+                hit_out[i] = best.hit ? 1 : 0;
+            } else {
+                if (pi.t) pi.t[i] = best.hit ? best.t : __builtin_inff();
+                if (pi.u) pi.u[i] = best.hit ? best.u : 0.f;
+                if (pi.v) pi.v[i] = best.hit ? best.v : 0.f;
+                if (pi.prim) pi.prim[i] = best.hit ? best.prim : 0u;
+                if (MODE == 2) {
+                    hf_si_rec si;
+                    if (best.hit) compute_si(f, o, d, best.t, best.u, best.v, best.prim, flags, si);
+                    else          miss_si(si, d, flags);
+                    store_si(sio, i, si, flags);
+                }
             }
         }
     }
@@ -340,21 +442,25 @@ static hf_si_dev to_dev(const hf_si_t *s) {
 }
 
 void hf_launch_trace(int mode, const hf_dev_field &f, size_t n, const hf_rays_t *rays, const uint8_t *active,
-                     const hf_pi_t *pi, uint8_t *hit, const hf_si_t *si, uint32_t flags, hipStream_t stream) {
+                     const hf_pi_t *pi, uint8_t *hit, const hf_si_t *si, uint32_t flags, unsigned long long *counter,
+                     hipStream_t stream) {
     if (n == 0) return;
+    (void) hipMemsetAsync(counter, 0, sizeof(unsigned long long), stream);
     hf_pi_dev p = { nullptr, nullptr, nullptr, nullptr };
     if (pi) { p.t = pi->t; p.u = pi->prim_uv[0]; p.v = pi->prim_uv[1]; p.prim = pi->prim_index; }
     hf_si_dev sd;
     memset(&sd, 0, sizeof(sd));
     if (si) sd = to_dev(si);
     const hf_rays_dev r = to_dev(rays);
-    const dim3 grid(grid_for(n)), block(HF_BLOCK);
+    size_t waves = (n + HF_GRAB - 1) / HF_GRAB, blocks = (waves + 3) / 4;
+    if (blocks > 256 * 6) blocks = 256 * 6;
+    const dim3 grid((unsigned) blocks), block(HF_BLOCK);
     if (mode == 0)
-        hipLaunchKernelGGL(hf_trace_kernel<0>, grid, block, 0, stream, f, n, r, active, p, hit, sd, flags);
+        hipLaunchKernelGGL(hf_trace_kernel<0>, grid, block, 0, stream, f, n, r, active, p, hit, sd, flags, counter);
     else if (mode == 1)
-        hipLaunchKernelGGL(hf_trace_kernel<1>, grid, block, 0, stream, f, n, r, active, p, hit, sd, flags);
+        hipLaunchKernelGGL(hf_trace_kernel<1>, grid, block, 0, stream, f, n, r, active, p, hit, sd, flags, counter);
     else
-        hipLaunchKernelGGL(hf_trace_kernel<2>, grid, block, 0, stream, f, n, r, active, p, hit, sd, flags);
+        hipLaunchKernelGGL(hf_trace_kernel<2>, grid, block, 0, stream, f, n, r, active, p, hit, sd, flags, counter);
 }
 
 // ---------------------------------------------------------------------------------

@@ -8,7 +8,8 @@
 void hf_launch_build_mips(const hf_dev_field &f, float2 *mip, hipStream_t stream);
 // mode 0: closest hit -> pi; 1: any hit -> hit; 2: closest hit + fused surface interaction
 void hf_launch_trace(int mode, const hf_dev_field &f, size_t n, const hf_rays_t *rays, const uint8_t *active,
-                     const hf_pi_t *pi, uint8_t *hit, const hf_si_t *si, uint32_t flags, hipStream_t stream);
+                     const hf_pi_t *pi, uint8_t *hit, const hf_si_t *si, uint32_t flags, unsigned long long *counter,
+                     hipStream_t stream);
 void hf_launch_si(const hf_dev_field &f, size_t n, const hf_rays_t *rays, const hf_pi_const_t *pi,
                   const uint8_t *active, const hf_si_t *si, uint32_t flags, hipStream_t stream);
 void hf_launch_adjoint(const hf_dev_field &f, size_t n, const hf_rays_t *rays, const hf_pi_const_t *pi,
