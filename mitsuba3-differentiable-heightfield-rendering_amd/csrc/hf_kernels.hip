@@ -124,28 +124,29 @@ __device__ __forceinline__ void stage_mips(const hf_dev_field &f, hf_lds_mips &s
 struct hf_trav {
     float gxm, gxp, gym, gyp; // origin x,y  +/- the xy margin m
     float gz, dz, idx, idy, mz;
+    float nx0, nx1, ny0, ny1; // order-space column/row (0 = near half, 1 = far half) of ACTUAL child column/row 0, 1
     uint32_t fxm, fym;        // mirror masks ((1<<top)-1 or 0)
     bool fx, fy;
 };
 
-// children of an inner node as 4 (min,max) boxes in ACTUAL child order j = 2*jy + jx
+// children of a node as 4 (min,max) boxes in ACTUAL child order j = 2*jy + jx
 struct hf_quad {
     float lo[4], hi[4];
 };
 
-// overlap mask (order-space child numbering k = 2*ky + kx) of the fat ray segment [0,thi]
-// with the four child boxes of the node whose order-space origin is (fX,fY), child size S.
+// Overlap mask (ACTUAL child numbering j = 2*jy + jx) of the fat ray segment [0,thi] with the
+// four child boxes of the node whose order-space origin is (fX,fY), child size S; tent[j] =
+// entry parameter of child j.  Direction is >= 0 in order space, so a child's entry planes are
+// its low faces and its exit planes its high faces; v_max3/v_min3 drop the NaN of 0*inf
+// (origin of an axis-parallel ray exactly on a face plane).
 __device__ __forceinline__ uint32_t child_mask(const hf_trav &r, float fX, float fY, float S, const hf_quad &q,
                                                float thi, float tent[4]) {
-    // t-intervals of the near / far half along x and y (direction >= 0 in order space);
-    // fmaxf/fminf below drop the NaN of 0*inf (origin exactly on a plane of an axis-parallel ray)
-    const float xn0 = (fX - r.gxm) * r.idx, xn1 = (fX + S - r.gxp) * r.idx;
-    const float xf0 = (fX + S - r.gxm) * r.idx, xf1 = (fX + (S + S) - r.gxp) * r.idx;
-    const float yn0 = (fY - r.gym) * r.idy, yn1 = (fY + S - r.gyp) * r.idy;
-    const float yf0 = (fY + S - r.gym) * r.idy, yf1 = (fY + (S + S) - r.gyp) * r.idy;
-    // actual child column 0 is the near half unless the axis is mirrored
-    const float x0lo = r.fx ? xf0 : xn0, x0hi = r.fx ? xf1 : xn1, x1lo = r.fx ? xn0 : xf0, x1hi = r.fx ? xn1 : xf1;
-    const float y0lo = r.fy ? yf0 : yn0, y0hi = r.fy ? yf1 : yn1, y1lo = r.fy ? yn0 : yf0, y1hi = r.fy ? yn1 : yf1;
+    const float ex = fX - r.gxm, lx = fX + S - r.gxp; // entry / exit plane offsets of order column 0
+    const float ey = fY - r.gym, ly = fY + S - r.gyp;
+    const float x0lo = __builtin_fmaf(S, r.nx0, ex) * r.idx, x0hi = __builtin_fmaf(S, r.nx0, lx) * r.idx;
+    const float x1lo = __builtin_fmaf(S, r.nx1, ex) * r.idx, x1hi = __builtin_fmaf(S, r.nx1, lx) * r.idx;
+    const float y0lo = __builtin_fmaf(S, r.ny0, ey) * r.idy, y0hi = __builtin_fmaf(S, r.ny0, ly) * r.idy;
+    const float y1lo = __builtin_fmaf(S, r.ny1, ey) * r.idy, y1hi = __builtin_fmaf(S, r.ny1, ly) * r.idy;
     uint32_t m = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -165,6 +166,27 @@ __device__ __forceinline__ uint32_t to_order(uint32_t m, bool fx, bool fy) {
     if (fx) m = ((m & 5u) << 1) | ((m >> 1) & 5u);
     if (fy) m = ((m & 3u) << 2) | ((m >> 2) & 3u);
     return m;
+}
+
+// fetch the 4 child boxes of inner node (X,Y,L), L >= 2, and return its pending-children mask
+__device__ __forceinline__ uint32_t expand_node(const hf_dev_field &f, const hf_lds_mips &s, const hf_trav &r,
+                                                uint32_t X, uint32_t Y, int L, int cw, float thi) {
+    const uint32_t ix = X ^ (r.fxm >> L), iy = Y ^ (r.fym >> L);
+    const uint32_t blk = 4u * (iy * (uint32_t) hf_level_w(cw, L) + ix);
+    float4 a, b;
+    if (L - 1 >= s.lo) {
+        const float4 *c = (const float4 *) (s.node + s.loff[L - 1] + blk);
+        a = c[0]; b = c[1];
+    } else {
+        const float4 *c = (const float4 *) (f.mip + s.goff[L - 1] + blk);
+        a = c[0]; b = c[1];
+    }
+    hf_quad q;
+    q.lo[0] = a.x; q.hi[0] = a.y; q.lo[1] = a.z; q.hi[1] = a.w;
+    q.lo[2] = b.x; q.hi[2] = b.y; q.lo[3] = b.z; q.hi[3] = b.w;
+    const float S = (float) (1u << (L - 1));
+    float tent[4];
+    return to_order(child_mask(r, (float) X * (S + S), (float) Y * (S + S), S, q, thi, tent), r.fx, r.fy);
 }
 
 template <bool ANY>
@@ -227,44 +249,31 @@ __device__ __forceinline__ void trace_ray(const hf_dev_field &f, const hf_lds_mi
     thi = thi + thi * 1e-6f + 1e-30f;
     r.fxm = r.fx ? ((1u << top) - 1u) : 0u;
     r.fym = r.fy ? ((1u << top) - 1u) : 0u;
+    r.nx0 = r.fx ? 1.f : 0.f; r.nx1 = 1.f - r.nx0;
+    r.ny0 = r.fy ? 1.f : 0.f; r.ny1 = 1.f - r.ny0;
 
     // walk: (X,Y,L) = current inner node in order space, `cur` = its children still to visit
     // (bit k = order-space child 2*ky+kx), `stk` = the same masks of the ancestors, 4 bits each.
     uint32_t X = 0, Y = 0, cur = 0;
     int L = top;
     uint64_t stk = 0;
-    bool done = false, have = (top == 1); // top == 1: the root itself is a leaf parent
+    bool done = false, have = (top == 1); // top == 1: the root itself is a level-1 node
     uint32_t lX = 0, lY = 0;
-    bool fresh = (top > 1);               // root needs expanding
+    if (top > 1) cur = expand_node(f, s, r, 0u, 0u, top, cw, thi);
+#ifdef HF_STATS
+    uint32_t n_expand = 1, n_leafp = 0, n_cells = 0, n_iter = 0;
+#endif
     for (;;) {
         // ---- phase 1: inner nodes, until this lane holds a level-1 node (2x2 cells) to test ----
         while (!done && !have) {
-            if (fresh) { // expand node (X,Y,L), L >= 2: fetch its 4 child boxes, build the pending mask
-                fresh = false;
-                const uint32_t ix = X ^ (r.fxm >> L), iy = Y ^ (r.fym >> L);
-                const uint32_t blk = 4u * (iy * (uint32_t) hf_level_w(cw, L) + ix);
-                float4 a, b;
-                if (L - 1 >= s.lo) {
-                    const float4 *c = (const float4 *) (s.node + s.loff[L - 1] + blk);
-                    a = c[0]; b = c[1];
-                } else {
-                    const float4 *c = (const float4 *) (f.mip + s.goff[L - 1] + blk);
-                    a = c[0]; b = c[1];
-                }
-                hf_quad q;
-                q.lo[0] = a.x; q.hi[0] = a.y; q.lo[1] = a.z; q.hi[1] = a.w;
-                q.lo[2] = b.x; q.hi[2] = b.y; q.lo[3] = b.z; q.hi[3] = b.w;
-                const float S = (float) (1u << (L - 1));
-                float tent[4];
-                cur = to_order(child_mask(r, (float) X * (S + S), (float) Y * (S + S), S, q, thi, tent), r.fx, r.fy);
-                continue;
-            }
-            if (cur == 0u) { // node exhausted: pop
-                if (L == top) { done = true; continue; }
+#ifdef HF_STATS
+            ++n_iter;
+#endif
+            while (cur == 0u && L < top) { // node exhausted: pop
                 cur = (uint32_t) stk & 15u; stk >>= 4;
                 X >>= 1; Y >>= 1; ++L;
-                continue;
             }
+            if (cur == 0u) { done = true; break; }
             const uint32_t k = (uint32_t) __builtin_ctz(cur);
             cur &= cur - 1u;
             const uint32_t cx = 2u * X + (k & 1u), cy = 2u * Y + (k >> 1);
@@ -272,12 +281,19 @@ __device__ __forceinline__ void trace_ray(const hf_dev_field &f, const hf_lds_mi
             const float S = (float) (1u << (L - 1));
             const float te = fmaxf(((float) cx * S - r.gxm) * r.idx, ((float) cy * S - r.gym) * r.idy);
             if (te > thi) continue;
-            if (L == 2) { have = true; lX = cx; lY = cy; continue; }
+            if (L == 2) { have = true; lX = cx; lY = cy; break; }
             stk = (stk << 4) | (uint64_t) cur;
-            X = cx; Y = cy; --L; fresh = true;
+            X = cx; Y = cy; --L;
+#ifdef HF_STATS
+            ++n_expand;
+#endif
+            cur = expand_node(f, s, r, X, Y, L, cw, thi);
         }
         if (!have) break;
         have = false;
+#ifdef HF_STATS
+        ++n_leafp;
+#endif
         // ---- phase 2: the 2x2 cells of level-1 node (lX,lY): 3x3 heights, then triangles ----
         {
             const uint32_t ix = lX ^ (r.fxm >> 1), iy = lY ^ (r.fym >> 1);
@@ -309,6 +325,9 @@ __device__ __forceinline__ void trace_ray(const hf_dev_field &f, const hf_lds_mi
                         const float b = (j == 0) ? z01 : (j == 1) ? z02 : (j == 2) ? z11 : z12;
                         const float c = (j == 0) ? z10 : (j == 1) ? z11 : (j == 2) ? z20 : z21;
                         const float e = (j == 0) ? z11 : (j == 1) ? z12 : (j == 2) ? z21 : z22;
+#ifdef HF_STATS
+                        ++n_cells;
+#endif
                         if (test_cell(f, c0 + (j & 1), r0 + (j >> 1), a, b, c, e, oo, od, maxt, best)) {
                             hit_any = true;
                             float tb = best.t - tin;
@@ -322,6 +341,10 @@ __device__ __forceinline__ void trace_ray(const hf_dev_field &f, const hf_lds_mi
             if (top == 1) break; // single leaf parent: nothing else to visit
         }
     }
+#ifdef HF_STATS
+    best.u = (float) n_expand + 1000.f * (float) n_leafp; best.v = (float) n_cells + 1000.f * (float) n_iter;
+    if (!best.hit) { best.hit = true; best.t = -1.f; }
+#endif
 }
 
 struct hf_rays_dev {
@@ -368,7 +391,7 @@ __device__ __forceinline__ void miss_si(hf_si_rec &si, v3 d, uint32_t flags) {
     si.wi = neg3(d);
 }
 
-#define HF_GRAB 128 // rays a wave takes from the work counter per fetch
+#define HF_GRAB 512 // rays a wave takes from the work counter per fetch
 
 // Persistent waves: every wave pulls HF_GRAB consecutive rays at a time from a global
 // counter (zeroed on the stream before the launch), so expensive image regions are

@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Run individual libhf kernels on the bench workload (for rocprofv3 / A-B timing).
+usage: python tools/prof_kernels.py [--grid 4096 --film 1024 --spp 64 --iters 5] kinds...
+kinds: fwd prelim si adj test miss mips"""
+import argparse, ctypes as C, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import hf_amd
+from hf_amd import _capi, build
+if os.environ.get('HF_LIB'):
+    build.LIB_PATH = os.environ['HF_LIB']; _capi._build.LIB_PATH = os.environ['HF_LIB']
+from hf_amd.shape import _DIFF_ROWS, _fill, _rows
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--grid", type=int, default=4096)
+ap.add_argument("--film", type=int, default=1024)
+ap.add_argument("--spp", type=int, default=64)
+ap.add_argument("--iters", type=int, default=5)
+ap.add_argument("kinds", nargs="*", default=["fwd", "prelim", "si", "adj", "test", "miss", "mips"])
+a = ap.parse_args()
+dev = torch.device("cuda", 0)
+N, R = a.grid, a.film * a.film * a.spp
+lib = _capi.lib()
+shape = hf_amd.Heightfield(heightfield=hf_amd.workload.sine_heights(N, N, device=dev), max_height=0.5)
+rays = hf_amd.workload.ortho_rays(a.film, a.film, a.spp, dev)
+t = torch.empty(R, device=dev); uv = torch.empty((2, R), device=dev); prim = torch.empty(R, dtype=torch.int32, device=dev)
+si = torch.empty((18, R), device=dev); gsi = torch.zeros((18, R), device=dev)
+hit8 = torch.empty(R, dtype=torch.uint8, device=dev)
+grad_h = torch.zeros((N, N), device=dev)
+st = torch.cuda.current_stream(dev).cuda_stream
+r_s = shape._rays_struct(rays[0:3], rays[3:6], rays[6]); pi_s = shape._pi_struct(t, uv, prim)
+si_s = _fill(_capi.hf_si_t(), _DIFF_ROWS, _rows(si, R)); g_s = _fill(_capi.hf_si_grad_t(), _DIFF_ROWS, _rows(gsi, R))
+flags = int(hf_amd.RayFlags.All)
+miss = rays.clone(); miss[5] = 1.0; miss[3] = 0; miss[4] = 0; miss[2] = 5.0   # pointing up, above the box
+m_s = shape._rays_struct(miss[0:3], miss[3:6], miss[6])
+fn = {
+    "fwd": lambda: _capi.check(lib.hf_ray_intersect(shape._h, R, C.byref(r_s), flags, None, C.byref(pi_s), C.byref(si_s), st)),
+    "prelim": lambda: _capi.check(lib.hf_ray_intersect_preliminary(shape._h, R, C.byref(r_s), None, C.byref(pi_s), st)),
+    "si": lambda: _capi.check(lib.hf_compute_surface_interaction(shape._h, R, C.byref(r_s), C.byref(pi_s), flags, None, C.byref(si_s), st)),
+    "adj": lambda: _capi.check(lib.hf_adjoint(shape._h, R, C.byref(r_s), C.byref(pi_s), flags, None, C.byref(g_s), grad_h.data_ptr(), None, None, st)),
+    "test": lambda: _capi.check(lib.hf_ray_test(shape._h, R, C.byref(r_s), None, hit8.data_ptr(), st)),
+    "miss": lambda: _capi.check(lib.hf_ray_intersect(shape._h, R, C.byref(m_s), flags, None, C.byref(pi_s), C.byref(si_s), st)),
+    "mips": lambda: shape.parameters_changed(["heightfield"]),
+}
+fn["fwd"](); torch.cuda.synchronize()
+h = torch.isfinite(si[0]); gsi[0] = h.float(); gsi[1:4] = si[4:7] * h
+for k in a.kinds:
+    fn[k](); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(a.iters): fn[k]()
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / a.iters
+    print(f"{k:7s} {ms:9.3f} ms  {R / ms / 1e3:10.1f} Mrays/s", flush=True)
