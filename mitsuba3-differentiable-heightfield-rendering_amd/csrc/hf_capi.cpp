@@ -115,13 +115,9 @@ extern "C" int hf_create(const hf_desc_t *desc, hf_field_t **out) {
     int top = 0;
     while ((1 << top) < cw || (1 << top) < ch) ++top;
     if (top < 1) top = 1;
-    if (top > 16) { free(hf); return fail(HF_EINVAL, "hf_create: grid too large (more than 65536 cells per side)"); }
+    if (top > 15) { free(hf); return fail(HF_EINVAL, "hf_create: grid too large (more than 32768 cells per side)"); }
     d.top = top;
-    size_t off = 0;
-    for (int l = 1; l <= top; ++l) { // blocked level l: one 4-slot block per level-(l+1) node
-        d.moff[l] = (uint32_t) off;
-        off += 4 * (size_t) hf_level_w(cw, l + 1) * hf_level_w(ch, l + 1);
-    }
+    const size_t off = hf_depth_off(top); // (4^top - 1)/3 nodes, depths 0..top-1
     hf->mip_nodes = off;
     hipError_t e = hipMalloc((void **) &hf->d_heights, sizeof(float) * (size_t) d.W * d.H);
     if (e == hipSuccess) e = hipMalloc((void **) &hf->d_mip, sizeof(float2) * off);
@@ -200,19 +196,17 @@ extern "C" int hf_num_levels(const hf_field_t *hf) { return hf ? hf->dev.top : 0
 
 extern "C" int hf_get_mip(const hf_field_t *hf, int level, float *h_out, uint32_t *w, uint32_t *h) {
     if (!hf || level < 1 || level > hf->dev.top) return fail(HF_EINVAL, "hf_get_mip: bad level %d", level);
-    const int cw = hf->dev.W - 1, ch = hf->dev.H - 1;
-    const int wl = hf_level_w(cw, level), hl = hf_level_w(ch, level), wl1 = hf_level_w(cw, level + 1),
-              hl1 = hf_level_w(ch, level + 1);
+    const int cw = hf->dev.W - 1, ch = hf->dev.H - 1, k = hf->dev.top - level;
+    const int wl = hf_level_w(cw, level), hl = hf_level_w(ch, level);
     if (w) *w = (uint32_t) wl;
     if (h) *h = (uint32_t) hl;
-    if (h_out) { // un-block into row-major (min,max) pairs
-        std::vector<float> tmp(8 * (size_t) wl1 * hl1);
+    if (h_out) { // existing nodes of the padded level, row-major (min,max) pairs
+        std::vector<float> tmp(2 * ((size_t) 1 << (2 * k)));
         HF_HIP(hipEventSynchronize(hf->built));
-        HF_HIP(hipMemcpy(tmp.data(), hf->d_mip + hf->dev.moff[level], sizeof(float) * tmp.size(),
-                         hipMemcpyDeviceToHost));
+        HF_HIP(hipMemcpy(tmp.data(), hf->d_mip + hf_depth_off(k), sizeof(float) * tmp.size(), hipMemcpyDeviceToHost));
         for (int iy = 0; iy < hl; ++iy)
             for (int ix = 0; ix < wl; ++ix) {
-                const size_t slot = 4 * ((size_t) (iy >> 1) * wl1 + (ix >> 1)) + 2 * (iy & 1) + (ix & 1);
+                const size_t slot = ((size_t) iy << k) + ix;
                 h_out[2 * ((size_t) iy * wl + ix) + 0] = tmp[2 * slot + 0];
                 h_out[2 * ((size_t) iy * wl + ix) + 1] = tmp[2 * slot + 1];
             }
@@ -225,7 +219,7 @@ extern "C" int hf_bbox(hf_field_t *hf, float out[6]) {
     if (!hf || !out) return fail(HF_EINVAL, "hf_bbox: NULL argument");
     float zr[2];
     HF_HIP(hipEventSynchronize(hf->built));
-    HF_HIP(hipMemcpy(zr, hf->d_mip + hf->dev.moff[hf->dev.top], sizeof(zr), hipMemcpyDeviceToHost));
+    HF_HIP(hipMemcpy(zr, hf->d_mip, sizeof(zr), hipMemcpyDeviceToHost));
     const hf_dev_field &d = hf->dev;
     const float lo[3] = { fmaf(0.f, d.sx, -1.f), fmaf(0.f, d.sy, -1.f), zr[0] };
     const float hi[3] = { fmaf((float) (d.W - 1), d.sx, -1.f), fmaf((float) (d.H - 1), d.sy, -1.f), zr[1] };

@@ -21,71 +21,53 @@
 #include "hf_launch.h"
 
 #define HF_BLOCK 256
-#define HF_LDS_LEVELS 6           // top mip levels staged in LDS (4+4+16+64+256+1024 entries for a square grid)
-#define HF_LDS_NODES 1368
+#define HF_LDS_NODES 1365 // pyramid depths 0..5 (1+4+16+64+256+1024 nodes) staged in LDS
 
 // ---------------------------------------------------------------------------------
-// min/max mip pyramid (blocked layout, see hf_dev_field)
+// min/max mip pyramid (coarse-first, padded, dilated -- see hf_dev_field)
 // ---------------------------------------------------------------------------------
-// one thread per slot of level 1: slot = 4*block + k, block = (by*w2 + bx), node = (2bx+(k&1), 2by+(k>>1))
+// level 1: node (ix,iy) bounds cells [2ix-1, 2ix+2] x [2iy-1, 2iy+2], i.e. vertices [2ix-1, 2ix+3]^2
 __global__ __launch_bounds__(HF_BLOCK) void hf_mip_level1_kernel(const float *__restrict__ h, int W, int H, float s,
-                                                                float2 *__restrict__ out, int w1, int h1, int w2,
-                                                                int nslots) {
-    const int slot = blockIdx.x * HF_BLOCK + threadIdx.x;
-    if (slot >= nslots) return;
-    const int k = slot & 3, b = slot >> 2;
-    const int by = b / w2, bx = b - by * w2;
-    const int ix = 2 * bx + (k & 1), iy = 2 * by + (k >> 1);
+                                                                float2 *__restrict__ out, int sh) {
+    const int idx = blockIdx.x * HF_BLOCK + threadIdx.x;
+    if (idx >= (1 << (2 * sh))) return;
+    const int iy = idx >> sh, ix = idx & ((1 << sh) - 1);
     float mn = __builtin_inff(), mx = -__builtin_inff();
-    if (ix < w1 && iy < h1) {
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const int i = 2 * iy + a;
-            if (i >= H) break;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const int j = 2 * ix + c;
-                if (j < W) {
-                    const float z = h[(size_t) i * W + j] * s;
-                    mn = fminf(mn, z); mx = fmaxf(mx, z);
-                }
+    // existing cells of the dilated region (a node just outside the grid still bounds the
+    // grid cells within one cell of it), then their vertices
+    const int ci0 = max(2 * iy - 1, 0), ci1 = min(2 * iy + 2, H - 2);
+    const int cj0 = max(2 * ix - 1, 0), cj1 = min(2 * ix + 2, W - 2);
+    if (ci0 <= ci1 && cj0 <= cj1) {
+        for (int i = ci0; i <= ci1 + 1; ++i)
+            for (int j = cj0; j <= cj1 + 1; ++j) {
+                const float z = h[(size_t) i * W + j] * s;
+                mn = fminf(mn, z); mx = fmaxf(mx, z);
             }
-        }
     }
-    out[slot] = make_float2(mn, mx);
+    out[idx] = make_float2(mn, mx);
 }
 
-// level l >= 2 from level l-1: node (ix,iy) reduces block (iy*w_l + ix) of the level below
+// depth k from depth k+1: 2x2 reduce (the union of the children's dilated regions is the parent's)
 __global__ __launch_bounds__(HF_BLOCK) void hf_mip_reduce_kernel(const float2 *__restrict__ in, float2 *__restrict__ out,
-                                                                int wl, int hl, int wl1, int nslots) {
-    const int slot = blockIdx.x * HF_BLOCK + threadIdx.x;
-    if (slot >= nslots) return;
-    const int k = slot & 3, b = slot >> 2;
-    const int by = b / wl1, bx = b - by * wl1;
-    const int ix = 2 * bx + (k & 1), iy = 2 * by + (k >> 1);
-    float mn = __builtin_inff(), mx = -__builtin_inff();
-    if (ix < wl && iy < hl) {
-        const float4 *c = (const float4 *) (in + 4 * ((size_t) iy * wl + ix));
-        const float4 a = c[0], d = c[1];
-        mn = fminf(fminf(a.x, a.z), fminf(d.x, d.z));
-        mx = fmaxf(fmaxf(a.y, a.w), fmaxf(d.y, d.w));
-    }
-    out[slot] = make_float2(mn, mx);
+                                                                int sh) {
+    const int idx = blockIdx.x * HF_BLOCK + threadIdx.x;
+    if (idx >= (1 << (2 * sh))) return;
+    const int iy = idx >> sh, ix = idx & ((1 << sh) - 1);
+    const float2 *c = in + ((size_t) (2 * iy) << (sh + 1)) + 2 * ix;
+    const float2 a = c[0], b = c[1], d = c[(size_t) 1 << (sh + 1)], e = c[((size_t) 1 << (sh + 1)) + 1];
+    out[idx] = make_float2(fminf(fminf(a.x, b.x), fminf(d.x, e.x)), fmaxf(fmaxf(a.y, b.y), fmaxf(d.y, e.y)));
 }
 
 void hf_launch_build_mips(const hf_dev_field &f, float2 *mip, hipStream_t stream) {
-    const int cw = f.W - 1, ch = f.H - 1;
-    for (int l = 1; l <= f.top; ++l) {
-        const int wl = hf_level_w(cw, l), hl = hf_level_w(ch, l);
-        const int wl1 = hf_level_w(cw, l + 1), hl1 = hf_level_w(ch, l + 1);
-        const int nslots = 4 * wl1 * hl1;
-        const int grid = (nslots + HF_BLOCK - 1) / HF_BLOCK;
-        if (l == 1)
+    const int top = f.top;
+    for (int k = top - 1; k >= 0; --k) {
+        const int n = 1 << (2 * k), grid = (n + HF_BLOCK - 1) / HF_BLOCK;
+        if (k == top - 1)
             hipLaunchKernelGGL(hf_mip_level1_kernel, dim3(grid), dim3(HF_BLOCK), 0, stream, f.h, f.W, f.H, f.s,
-                               mip + f.moff[1], wl, hl, wl1, nslots);
+                               mip + hf_depth_off(k), k);
         else
             hipLaunchKernelGGL(hf_mip_reduce_kernel, dim3(grid), dim3(HF_BLOCK), 0, stream,
-                               (const float2 *) (mip + f.moff[l - 1]), mip + f.moff[l], wl, hl, wl1, nslots);
+                               (const float2 *) (mip + hf_depth_off(k + 1)), mip + hf_depth_off(k), k);
     }
 }
 
@@ -93,30 +75,13 @@ void hf_launch_build_mips(const hf_dev_field &f, float2 *mip, hipStream_t stream
 // traversal
 // ---------------------------------------------------------------------------------
 struct hf_lds_mips {
-    float2 node[HF_LDS_NODES];
-    uint32_t goff[HF_MAX_LEVELS + 1]; // global offset (float2 units) of level l
-    uint32_t loff[HF_MAX_LEVELS + 1]; // LDS offset of level l (valid for l >= lo)
-    int lo;                           // lowest staged level
+    float2 node[HF_LDS_NODES]; // the first (coarsest) nodes of the pyramid
 };
 
 __device__ __forceinline__ void stage_mips(const hf_dev_field &f, hf_lds_mips &s) {
-    const int tid = threadIdx.x;
-    const int cw = f.W - 1, ch = f.H - 1;
-    // stage levels top, top-1, ... while they fit
-    int lo = f.top + 1;
-    uint32_t acc = 0;
-    for (int l = f.top; l >= 1 && l > f.top - HF_LDS_LEVELS; --l) {
-        const uint32_t cnt = 4u * (uint32_t) (hf_level_w(cw, l + 1) * hf_level_w(ch, l + 1));
-        if (acc + cnt > HF_LDS_NODES) break;
-        for (uint32_t k = tid; k < cnt; k += HF_BLOCK) s.node[acc + k] = f.mip[f.moff[l] + k];
-        if (tid == 0) s.loff[l] = acc;
-        acc += cnt;
-        lo = l;
-    }
-    if (tid == 0) {
-        for (int l = 1; l <= f.top; ++l) s.goff[l] = f.moff[l];
-        s.lo = lo;
-    }
+    const uint32_t total = hf_depth_off(f.top);
+    const uint32_t cnt = total < HF_LDS_NODES ? total : HF_LDS_NODES;
+    for (uint32_t k = threadIdx.x; k < cnt; k += HF_BLOCK) s.node[k] = f.mip[k];
     __syncthreads();
 }
 
@@ -125,20 +90,18 @@ struct hf_trav {
     float gxm, gxp, gym, gyp; // origin x,y  +/- the xy margin m
     float gz, dz, idx, idy, mz;
     float nx0, nx1, ny0, ny1; // order-space column/row (0 = near half, 1 = far half) of ACTUAL child column/row 0, 1
-    uint32_t fxm, fym;        // mirror masks ((1<<top)-1 or 0)
-    bool fx, fy;
 };
 
-// children of a node as 4 (min,max) boxes in ACTUAL child order j = 2*jy + jx
+// four cells as (min,max) boxes in ACTUAL order j = 2*jy + jx
 struct hf_quad {
     float lo[4], hi[4];
 };
 
-// Overlap mask (ACTUAL child numbering j = 2*jy + jx) of the fat ray segment [0,thi] with the
-// four child boxes of the node whose order-space origin is (fX,fY), child size S; tent[j] =
-// entry parameter of child j.  Direction is >= 0 in order space, so a child's entry planes are
-// its low faces and its exit planes its high faces; v_max3/v_min3 drop the NaN of 0*inf
-// (origin of an axis-parallel ray exactly on a face plane).
+// Overlap mask (ACTUAL numbering j = 2*jy + jx) of the fat ray segment [0,thi] with the four
+// boxes of the 2x2 block whose order-space origin is (fX,fY), box size S; tent[j] = entry
+// parameter of box j.  Direction is >= 0 in order space, so a box's entry planes are its low
+// faces and its exit planes its high faces; v_max3/v_min3 drop the NaN of 0*inf (origin of an
+// axis-parallel ray exactly on a face plane).
 __device__ __forceinline__ uint32_t child_mask(const hf_trav &r, float fX, float fY, float S, const hf_quad &q,
                                                float thi, float tent[4]) {
     const float ex = fX - r.gxm, lx = fX + S - r.gxp; // entry / exit plane offsets of order column 0
@@ -161,34 +124,12 @@ __device__ __forceinline__ uint32_t child_mask(const hf_trav &r, float fX, float
     return m;
 }
 
-// actual-child mask -> order-space child mask (bit k = bit (k ^ flip))
-__device__ __forceinline__ uint32_t to_order(uint32_t m, bool fx, bool fy) {
-    if (fx) m = ((m & 5u) << 1) | ((m >> 1) & 5u);
-    if (fy) m = ((m & 3u) << 2) | ((m >> 2) & 3u);
-    return m;
-}
-
-// fetch the 4 child boxes of inner node (X,Y,L), L >= 2, and return its pending-children mask
-__device__ __forceinline__ uint32_t expand_node(const hf_dev_field &f, const hf_lds_mips &s, const hf_trav &r,
-                                                uint32_t X, uint32_t Y, int L, int cw, float thi) {
-    const uint32_t ix = X ^ (r.fxm >> L), iy = Y ^ (r.fym >> L);
-    const uint32_t blk = 4u * (iy * (uint32_t) hf_level_w(cw, L) + ix);
-    float4 a, b;
-    if (L - 1 >= s.lo) {
-        const float4 *c = (const float4 *) (s.node + s.loff[L - 1] + blk);
-        a = c[0]; b = c[1];
-    } else {
-        const float4 *c = (const float4 *) (f.mip + s.goff[L - 1] + blk);
-        a = c[0]; b = c[1];
-    }
-    hf_quad q;
-    q.lo[0] = a.x; q.hi[0] = a.y; q.lo[1] = a.z; q.hi[1] = a.w;
-    q.lo[2] = b.x; q.hi[2] = b.y; q.lo[3] = b.z; q.hi[3] = b.w;
-    const float S = (float) (1u << (L - 1));
-    float tent[4];
-    return to_order(child_mask(r, (float) X * (S + S), (float) Y * (S + S), S, q, thi, tent), r.fx, r.fy);
-}
-
+// Hierarchical DDA.  The walk follows the ANCHOR a(t) = p(t) - (2m,2m) of the fat ray
+// (p = ray point in order space, m = xy margin): while a(t) is in node (X,Y) of some depth,
+// the fat square p +- m lies inside that node dilated by < 1 cell, which is what the dilated
+// mip entry bounds; at cell level it lies inside the 2x2 cell block anchored at a's cell.
+// Steps tile the parameter axis in increasing t, so the walk may stop as soon as a hit
+// precedes the end of the current step.
 template <bool ANY>
 __device__ __forceinline__ void trace_ray(const hf_dev_field &f, const hf_lds_mips &s, v3 o, v3 d, float maxt,
                                           hf_hit &best) {
@@ -201,7 +142,7 @@ __device__ __forceinline__ void trace_ray(const hf_dev_field &f, const hf_lds_mi
     }
     const int cw = f.W - 1, ch = f.H - 1, top = f.top;
     const float hx = 0.5f * (float) cw, hy = 0.5f * (float) ch;
-    const float2 zr = s.node[0]; // first staged entry = root of the pyramid = global (min z, max z)
+    const float2 zr = s.node[0]; // root of the pyramid = global (min z, max z)
     const float zspan = fmaxf(zr.y - zr.x, fmaxf(__builtin_fabsf(zr.x), __builtin_fabsf(zr.y)));
     const float mz0 = 1e-5f * zspan + 1e-30f;
 
@@ -231,91 +172,124 @@ __device__ __forceinline__ void trace_ray(const hf_dev_field &f, const hf_lds_mi
 
     // traversal ray in cell units, re-based at t = tin, mirrored into order space
     hf_trav r;
-    r.fx = od.x < 0.f; r.fy = od.y < 0.f;
+    const bool fx = od.x < 0.f, fy = od.y < 0.f;
     const float Wp = (float) (1 << top);
-    float gx = (__builtin_fmaf(tin, od.x, oo.x) + 1.f) * hx, gy = (__builtin_fmaf(tin, od.y, oo.y) + 1.f) * hy;
+    // entry point in double: keeps the walk accurate for origins far from the grid
+    float gx = (float) (((double) oo.x + (double) tin * (double) od.x + 1.0) * (double) hx);
+    float gy = (float) (((double) oo.y + (double) tin * (double) od.y + 1.0) * (double) hy);
     r.gz = __builtin_fmaf(tin, od.z, oo.z);
     float dx = od.x * hx, dy = od.y * hy;
     r.dz = od.z;
-    if (r.fx) { gx = Wp - gx; dx = -dx; }
-    if (r.fy) { gy = Wp - gy; dy = -dy; }
+    if (fx) { gx = Wp - gx; dx = -dx; }
+    if (fy) { gy = Wp - gy; dy = -dy; }
     r.idx = 1.0f / dx; r.idy = 1.0f / dy; // +inf for axis-parallel rays
     const float reach = __builtin_fabsf(oo.x) + __builtin_fabsf(oo.y) +
                         tin * (__builtin_fabsf(od.x) + __builtin_fabsf(od.y)) + 2.f;
-    const float m = 0.015625f + 4.8e-7f * reach * fmaxf(hx, hy);
+    // xy margin: covers the rounding of the walk and of the triangle test itself (which grows with
+    // the distance of the origin); the anchor scheme needs 3m < 1 cell, so it is capped -- beyond
+    // ~0.28/(4.8e-7*max(hx,hy)) object units from the grid the result is no longer guaranteed to be
+    // the brute force's bit for bit (the triangle test itself is noise at that distance).
+    const float m = fminf(0.015625f + 4.8e-7f * reach * fmaxf(hx, hy), 0.3f);
     r.mz = mz0 + 4.8e-7f * (__builtin_fabsf(oo.z) + tin * __builtin_fabsf(od.z) + zspan);
     r.gxm = gx + m; r.gxp = gx - m; r.gym = gy + m; r.gyp = gy - m;
     float thi = tout - tin;
     thi = thi + thi * 1e-6f + 1e-30f;
-    r.fxm = r.fx ? ((1u << top) - 1u) : 0u;
-    r.fym = r.fy ? ((1u << top) - 1u) : 0u;
-    r.nx0 = r.fx ? 1.f : 0.f; r.nx1 = 1.f - r.nx0;
-    r.ny0 = r.fy ? 1.f : 0.f; r.ny1 = 1.f - r.ny0;
+    const uint32_t fxm = fx ? ((1u << top) - 1u) : 0u, fym = fy ? ((1u << top) - 1u) : 0u;
+    r.nx0 = fx ? 1.f : 0.f; r.nx1 = 1.f - r.nx0;
+    r.ny0 = fy ? 1.f : 0.f; r.ny1 = 1.f - r.ny0;
 
-    // walk: (X,Y,L) = current inner node in order space, `cur` = its children still to visit
-    // (bit k = order-space child 2*ky+kx), `stk` = the same masks of the ancestors, 4 bits each.
-    uint32_t X = 0, Y = 0, cur = 0;
-    int L = top;
-    uint64_t stk = 0;
-    bool done = false, have = (top == 1); // top == 1: the root itself is a level-1 node
-    uint32_t lX = 0, lY = 0;
-    if (top > 1) cur = expand_node(f, s, r, 0u, 0u, top, cw, thi);
+    // anchor of the fat ray at t = 0
+    const float ax = gx - (m + m), ay = gy - (m + m);
+    // start a few levels above the cells; lev = quadtree level of the current node (0 = cell)
+    int lev = top > 4 ? 4 : top - 1;
+    if (lev < 0) lev = 0;
+    uint32_t X, Y;
+    {
+        const float is = 1.0f / (float) (1u << lev);
+        const float qx = fminf(fmaxf(ax * is, 0.f), Wp), qy = fminf(fmaxf(ay * is, 0.f), Wp);
+        X = (uint32_t) qx; Y = (uint32_t) qy; // floor of a non-negative value
+    }
+    float t_in = 0.f;
 #ifdef HF_STATS
-    uint32_t n_expand = 1, n_leafp = 0, n_cells = 0, n_iter = 0;
+    uint32_t n_expand = 0, n_leafp = 0, n_cells = 0, n_iter = 0;
 #endif
     for (;;) {
-        // ---- phase 1: inner nodes, until this lane holds a level-1 node (2x2 cells) to test ----
-        while (!done && !have) {
+        // ---- phase 1: mip steps until the anchor sits in a cell whose 2x2 block must be tested ----
+        bool have = false;
+        float t_out = 0.f;
+        for (;;) {
 #ifdef HF_STATS
             ++n_iter;
 #endif
-            while (cur == 0u && L < top) { // node exhausted: pop
-                cur = (uint32_t) stk & 15u; stk >>= 4;
-                X >>= 1; Y >>= 1; ++L;
-            }
-            if (cur == 0u) { done = true; break; }
-            const uint32_t k = (uint32_t) __builtin_ctz(cur);
-            cur &= cur - 1u;
-            const uint32_t cx = 2u * X + (k & 1u), cy = 2u * Y + (k >> 1);
-            // the mask may predate a hit: re-check the child's entry against the current t_hi
-            const float S = (float) (1u << (L - 1));
-            const float te = fmaxf(((float) cx * S - r.gxm) * r.idx, ((float) cy * S - r.gym) * r.idy);
-            if (te > thi) continue;
-            if (L == 2) { have = true; lX = cx; lY = cy; break; }
-            stk = (stk << 4) | (uint64_t) cur;
-            X = cx; Y = cy; --L;
+            const uint32_t n = 1u << (top - lev); // nodes per row at this level
+            if (X >= n || Y >= n) break;          // walked off the (padded) grid
+            const float S = (float) (1u << lev);
+            const float tox = ((float) (X + 1u) * S - ax) * r.idx, toy = ((float) (Y + 1u) * S - ay) * r.idy;
+            t_out = fminf(tox, toy); // anchor leaves the node (NaN of 0*inf dropped)
+            bool overlap = true;
+            if (lev > 0) {
+                const uint32_t ix = X ^ (fxm >> lev), iy = Y ^ (fym >> lev);
+                const uint32_t k = (uint32_t) (top - lev);
+                const uint32_t a = (0x55555555u & ((1u << (2u * k)) - 1u)) + (iy << k) + ix;
+                float2 mm;
+                if (a < HF_LDS_NODES) mm = s.node[a];
+                else                  mm = f.mip[a];
+                const float te = fminf(t_out, thi);
+                const float za = __builtin_fmaf(t_in, r.dz, r.gz), zb = __builtin_fmaf(te, r.dz, r.gz);
+                overlap = (fminf(za, zb) - r.mz <= mm.y) & (fmaxf(za, zb) + r.mz >= mm.x);
 #ifdef HF_STATS
-            ++n_expand;
+                ++n_expand;
 #endif
-            cur = expand_node(f, s, r, X, Y, L, cw, thi);
+            }
+            if (overlap) {
+                if (lev == 0) { have = true; break; }
+                // descend into the child that holds the anchor at t_in
+                --lev;
+                const float Sc = (float) (1u << lev);
+                const float tmx = ((float) (2u * X + 1u) * Sc - ax) * r.idx, tmy = ((float) (2u * Y + 1u) * Sc - ay) * r.idy;
+                X = 2u * X + ((tmx <= t_in) ? 1u : 0u);
+                Y = 2u * Y + ((tmy <= t_in) ? 1u : 0u);
+                continue;
+            }
+            // skip this node: step to the neighbour the anchor enters and climb while aligned
+            if (!(t_out < thi)) { lev = -1; break; }
+            t_in = t_out;
+            int c;
+            if (tox <= toy) { ++X; c = __builtin_ctz(X | 0x80000000u); }
+            else            { ++Y; c = __builtin_ctz(Y | 0x80000000u); }
+            c = min(c, top - 1 - lev);
+            c = max(c, 0);
+            X >>= c; Y >>= c; lev += c;
         }
         if (!have) break;
-        have = false;
 #ifdef HF_STATS
         ++n_leafp;
 #endif
-        // ---- phase 2: the 2x2 cells of level-1 node (lX,lY): 3x3 heights, then triangles ----
+        // ---- phase 2: the 2x2 cell block anchored at order-space cell (X,Y): 3x3 heights, triangles ----
         {
-            const uint32_t ix = lX ^ (r.fxm >> 1), iy = lY ^ (r.fym >> 1);
-            const int c0 = (int) (2u * ix), r0 = (int) (2u * iy);
-            const int c1 = min(c0 + 1, f.W - 1), c2 = min(c0 + 2, f.W - 1);
-            const int r1 = min(r0 + 1, f.H - 1), r2 = min(r0 + 2, f.H - 1);
-            const float *p0 = f.h + (size_t) r0 * f.W, *p1 = f.h + (size_t) r1 * f.W, *p2 = f.h + (size_t) r2 * f.W;
-            const float z00 = p0[c0] * f.s, z01 = p0[c1] * f.s, z02 = p0[c2] * f.s;
-            const float z10 = p1[c0] * f.s, z11 = p1[c1] * f.s, z12 = p1[c2] * f.s;
-            const float z20 = p2[c0] * f.s, z21 = p2[c1] * f.s, z22 = p2[c2] * f.s;
-            const bool vx1 = c0 + 1 < cw, vy1 = r0 + 1 < ch; // cells (c0,r0) always exist
+            // actual lower-left cell of the block (order column X+1 is the lower actual one when mirrored)
+            const int c0 = fx ? ((1 << top) - 2 - (int) X) : (int) X;
+            const int r0 = fy ? ((1 << top) - 2 - (int) Y) : (int) Y;
+            const int ca = min(max(c0, 0), f.W - 1), cb = min(max(c0 + 1, 0), f.W - 1), cc = min(max(c0 + 2, 0), f.W - 1);
+            const int ra = min(max(r0, 0), f.H - 1), rb = min(max(r0 + 1, 0), f.H - 1), rc = min(max(r0 + 2, 0), f.H - 1);
+            const float *p0 = f.h + (size_t) ra * f.W, *p1 = f.h + (size_t) rb * f.W, *p2 = f.h + (size_t) rc * f.W;
+            const float z00 = p0[ca] * f.s, z01 = p0[cb] * f.s, z02 = p0[cc] * f.s;
+            const float z10 = p1[ca] * f.s, z11 = p1[cb] * f.s, z12 = p1[cc] * f.s;
+            const float z20 = p2[ca] * f.s, z21 = p2[cb] * f.s, z22 = p2[cc] * f.s;
+            const bool vx0 = (c0 >= 0) & (c0 < cw), vx1 = (c0 + 1 >= 0) & (c0 + 1 < cw);
+            const bool vy0 = (r0 >= 0) & (r0 < ch), vy1 = (r0 + 1 >= 0) & (r0 + 1 < ch);
             const float inf = __builtin_inff();
             hf_quad q;
-            q.lo[0] = fminf(fminf(z00, z01), fminf(z10, z11)); q.hi[0] = fmaxf(fmaxf(z00, z01), fmaxf(z10, z11));
-            q.lo[1] = vx1 ? fminf(fminf(z01, z02), fminf(z11, z12)) : inf;
-            q.hi[1] = vx1 ? fmaxf(fmaxf(z01, z02), fmaxf(z11, z12)) : -inf;
-            q.lo[2] = vy1 ? fminf(fminf(z10, z11), fminf(z20, z21)) : inf;
-            q.hi[2] = vy1 ? fmaxf(fmaxf(z10, z11), fmaxf(z20, z21)) : -inf;
+            q.lo[0] = (vx0 & vy0) ? fminf(fminf(z00, z01), fminf(z10, z11)) : inf;
+            q.hi[0] = (vx0 & vy0) ? fmaxf(fmaxf(z00, z01), fmaxf(z10, z11)) : -inf;
+            q.lo[1] = (vx1 & vy0) ? fminf(fminf(z01, z02), fminf(z11, z12)) : inf;
+            q.hi[1] = (vx1 & vy0) ? fmaxf(fmaxf(z01, z02), fmaxf(z11, z12)) : -inf;
+            q.lo[2] = (vx0 & vy1) ? fminf(fminf(z10, z11), fminf(z20, z21)) : inf;
+            q.hi[2] = (vx0 & vy1) ? fmaxf(fmaxf(z10, z11), fmaxf(z20, z21)) : -inf;
             q.lo[3] = (vx1 & vy1) ? fminf(fminf(z11, z12), fminf(z21, z22)) : inf;
             q.hi[3] = (vx1 & vy1) ? fmaxf(fmaxf(z11, z12), fmaxf(z21, z22)) : -inf;
             float tent[4];
-            const uint32_t cm = child_mask(r, (float) lX * 2.f, (float) lY * 2.f, 1.f, q, thi, tent);
+            const uint32_t cm = child_mask(r, (float) X, (float) Y, 1.f, q, thi, tent);
             bool hit_any = false;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -338,7 +312,16 @@ __device__ __forceinline__ void trace_ray(const hf_dev_field &f, const hf_lds_mi
                 }
             }
             if (ANY && hit_any) break;
-            if (top == 1) break; // single leaf parent: nothing else to visit
+            // every cell the fat ray touches before t_out has now been tested: a hit that
+            // precedes t_out is final.  (thi already carries the hit plus its margin.)
+            if (!(t_out < thi)) break;
+            t_in = t_out;
+            const float tox = ((float) (X + 1u) - ax) * r.idx, toy = ((float) (Y + 1u) - ay) * r.idy;
+            int c;
+            if (tox <= toy) { ++X; c = __builtin_ctz(X | 0x80000000u); }
+            else            { ++Y; c = __builtin_ctz(Y | 0x80000000u); }
+            c = min(c, top - 1);
+            X >>= c; Y >>= c; lev = c;
         }
     }
 #ifdef HF_STATS
