@@ -124,25 +124,30 @@ __device__ __forceinline__ uint32_t child_mask(const hf_trav &r, float fX, float
     return m;
 }
 
-// Hierarchical DDA.  The walk follows the ANCHOR a(t) = p(t) - (2m,2m) of the fat ray
-// (p = ray point in order space, m = xy margin): while a(t) is in node (X,Y) of some depth,
-// the fat square p +- m lies inside that node dilated by < 1 cell, which is what the dilated
-// mip entry bounds; at cell level it lies inside the 2x2 cell block anchored at a's cell.
-// Steps tile the parameter axis in increasing t, so the walk may stop as soon as a hit
-// precedes the end of the current step.
-template <bool ANY>
-__device__ __forceinline__ void trace_ray(const hf_dev_field &f, const hf_lds_mips &s, v3 o, v3 d, float maxt,
-                                          hf_hit &best) {
-    best.hit = false; best.t = __builtin_inff(); best.u = 0.f; best.v = 0.f; best.prim = 0u;
+// everything a lane needs to walk its ray: object-space ray (spec arithmetic input of the
+// triangle test) + traversal constants in order space
+struct hf_ray_state {
+    v3 oo, od;
+    float maxt, tin, thi;
+    float gx, gy, m; // order-space entry point (cell units) and xy margin
+    hf_trav r;
+    bool fx, fy;
+};
+
+// transform to object space, clip against the inflated bound, build the traversal ray.
+// returns false when the ray cannot hit (outside the bound, non-finite, bad maxt).
+__device__ __forceinline__ bool setup_ray(const hf_dev_field &f, float2 zr, v3 o, v3 d, float maxt,
+                                          hf_ray_state &rs) {
+    hf_trav &r = rs.r;
     const v3 oo = xform_point(f.to_object, o), od = xform_vec(f.to_object, d);
+    rs.oo = oo; rs.od = od; rs.maxt = maxt;
     // non-finite input or NaN/negative maxt: miss (also bounds the walk below)
     {
         const float chk = (oo.x + oo.y + oo.z) + (od.x + od.y + od.z);
-        if (!(__builtin_fabsf(chk) < __builtin_inff()) || !(maxt >= 0.f)) return;
+        if (!(__builtin_fabsf(chk) < __builtin_inff()) || !(maxt >= 0.f)) return false;
     }
     const int cw = f.W - 1, ch = f.H - 1, top = f.top;
     const float hx = 0.5f * (float) cw, hy = 0.5f * (float) ch;
-    const float2 zr = s.node[0]; // root of the pyramid = global (min z, max z)
     const float zspan = fmaxf(zr.y - zr.x, fmaxf(__builtin_fabsf(zr.x), __builtin_fabsf(zr.y)));
     const float mz0 = 1e-5f * zspan + 1e-30f;
 
@@ -167,11 +172,10 @@ __device__ __forceinline__ void trace_ray(const hf_dev_field &f, const hf_lds_mi
         tin = tin - __builtin_fabsf(tin) * 1e-6f;
         tin = fmaxf(tin, 0.f);
         tout = tout + __builtin_fabsf(tout) * 1e-6f;
-        if (outside || !(tin <= tout)) return;
+        if (outside || !(tin <= tout)) return false;
     }
 
     // traversal ray in cell units, re-based at t = tin, mirrored into order space
-    hf_trav r;
     const bool fx = od.x < 0.f, fy = od.y < 0.f;
     const float Wp = (float) (1 << top);
     // entry point in double: keeps the walk accurate for origins far from the grid
@@ -194,10 +198,94 @@ __device__ __forceinline__ void trace_ray(const hf_dev_field &f, const hf_lds_mi
     r.gxm = gx + m; r.gxp = gx - m; r.gym = gy + m; r.gyp = gy - m;
     float thi = tout - tin;
     thi = thi + thi * 1e-6f + 1e-30f;
-    const uint32_t fxm = fx ? ((1u << top) - 1u) : 0u, fym = fy ? ((1u << top) - 1u) : 0u;
     r.nx0 = fx ? 1.f : 0.f; r.nx1 = 1.f - r.nx0;
     r.ny0 = fy ? 1.f : 0.f; r.ny1 = 1.f - r.ny0;
 
+    rs.tin = tin; rs.thi = thi; rs.gx = gx; rs.gy = gy; rs.m = m; rs.fx = fx; rs.fy = fy;
+    return true;
+}
+
+// 3x3 heights -> the 2x2 cells of a block as boxes, exact fat-ray test per cell, triangles.
+// (c0,r0) = actual lower-left cell of the block, (fX,fY) = its order-space origin.
+// Returns true if any triangle was hit; best/thi are updated.
+template <typename LoadH>
+__device__ __forceinline__ bool test_block(const hf_dev_field &f, const hf_ray_state &rs, const hf_trav &r, int c0,
+                                           int r0, float fX, float fY, float t_in, float t_out, bool prereject,
+                                           float &thi, hf_hit &best, LoadH loadh
+#ifdef HF_STATS
+                                           , uint32_t &n_cells
+#endif
+) {
+    const int cw = f.W - 1, ch = f.H - 1;
+    const int ca = min(max(c0, 0), f.W - 1), cb = min(max(c0 + 1, 0), f.W - 1), cc = min(max(c0 + 2, 0), f.W - 1);
+    const int ra = min(max(r0, 0), f.H - 1), rb = min(max(r0 + 1, 0), f.H - 1), rc = min(max(r0 + 2, 0), f.H - 1);
+    const float z00 = loadh(ra, ca) * f.s, z01 = loadh(ra, cb) * f.s, z02 = loadh(ra, cc) * f.s;
+    const float z10 = loadh(rb, ca) * f.s, z11 = loadh(rb, cb) * f.s, z12 = loadh(rb, cc) * f.s;
+    const float z20 = loadh(rc, ca) * f.s, z21 = loadh(rc, cb) * f.s, z22 = loadh(rc, cc) * f.s;
+    const bool vx0 = (c0 >= 0) & (c0 < cw), vx1 = (c0 + 1 >= 0) & (c0 + 1 < cw);
+    const bool vy0 = (r0 >= 0) & (r0 < ch), vy1 = (r0 + 1 >= 0) & (r0 + 1 < ch);
+    const float inf = __builtin_inff();
+    uint32_t cm = 0;
+    float tent[4] = { 0.f, 0.f, 0.f, 0.f };
+    bool go = true;
+    if (prereject) { // ray z over this step vs the bounds of all 9 heights
+        const float lo9 = fminf(fminf(fminf(fminf(z00, z01), fminf(z02, z10)), fminf(fminf(z11, z12), fminf(z20, z21))), z22);
+        const float hi9 = fmaxf(fmaxf(fmaxf(fmaxf(z00, z01), fmaxf(z02, z10)), fmaxf(fmaxf(z11, z12), fmaxf(z20, z21))), z22);
+        const float te = fminf(t_out, thi);
+        const float za = __builtin_fmaf(t_in, r.dz, r.gz), zb = __builtin_fmaf(te, r.dz, r.gz);
+        go = (fminf(za, zb) - r.mz <= hi9) & (fmaxf(za, zb) + r.mz >= lo9);
+    }
+    if (go) {
+        hf_quad q;
+        q.lo[0] = (vx0 & vy0) ? fminf(fminf(z00, z01), fminf(z10, z11)) : inf;
+        q.hi[0] = (vx0 & vy0) ? fmaxf(fmaxf(z00, z01), fmaxf(z10, z11)) : -inf;
+        q.lo[1] = (vx1 & vy0) ? fminf(fminf(z01, z02), fminf(z11, z12)) : inf;
+        q.hi[1] = (vx1 & vy0) ? fmaxf(fmaxf(z01, z02), fmaxf(z11, z12)) : -inf;
+        q.lo[2] = (vx0 & vy1) ? fminf(fminf(z10, z11), fminf(z20, z21)) : inf;
+        q.hi[2] = (vx0 & vy1) ? fmaxf(fmaxf(z10, z11), fmaxf(z20, z21)) : -inf;
+        q.lo[3] = (vx1 & vy1) ? fminf(fminf(z11, z12), fminf(z21, z22)) : inf;
+        q.hi[3] = (vx1 & vy1) ? fmaxf(fmaxf(z11, z12), fmaxf(z21, z22)) : -inf;
+        cm = child_mask(r, fX, fY, 1.f, q, thi, tent);
+    }
+    bool hit_any = false;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (__ballot(((cm >> j) & 1u) && tent[j] <= thi) == 0ull) continue; // no lane of the wave needs cell j
+        if (((cm >> j) & 1u) && tent[j] <= thi) {
+            const float a = (j == 0) ? z00 : (j == 1) ? z01 : (j == 2) ? z10 : z11;
+            const float b = (j == 0) ? z01 : (j == 1) ? z02 : (j == 2) ? z11 : z12;
+            const float c = (j == 0) ? z10 : (j == 1) ? z11 : (j == 2) ? z20 : z21;
+            const float e = (j == 0) ? z11 : (j == 1) ? z12 : (j == 2) ? z21 : z22;
+#ifdef HF_STATS
+            ++n_cells;
+#endif
+            if (test_cell(f, c0 + (j & 1), r0 + (j >> 1), a, b, c, e, rs.oo, rs.od, rs.maxt, best)) {
+                hit_any = true;
+                float tb = best.t - rs.tin;
+                tb = tb + __builtin_fabsf(tb) * 1e-6f + 1e-30f;
+                thi = fminf(thi, tb);
+            }
+        }
+    }
+    return hit_any;
+}
+
+// Hierarchical DDA (per-lane walk; used for waves whose rays are not coherent).
+// The walk follows the ANCHOR a(t) = p(t) - (2m,2m) of the fat ray
+// (p = ray point in order space, m = xy margin): while a(t) is in node (X,Y) of some depth,
+// the fat square p +- m lies inside that node dilated by < 1 cell, which is what the dilated
+// mip entry bounds; at cell level it lies inside the 2x2 cell block anchored at a's cell.
+// Steps tile the parameter axis in increasing t, so the walk may stop as soon as a hit
+// precedes the end of the current step.
+template <bool ANY>
+__device__ __forceinline__ void walk_dda(const hf_dev_field &f, const hf_lds_mips &s, const hf_ray_state &rs,
+                                         hf_hit &best) {
+    const hf_trav &r = rs.r;
+    const int top = f.top;
+    const bool fx = rs.fx, fy = rs.fy;
+    const float gx = rs.gx, gy = rs.gy, m = rs.m, Wp = (float) (1 << top);
+    float thi = rs.thi;
+    const uint32_t fxm = fx ? ((1u << top) - 1u) : 0u, fym = fy ? ((1u << top) - 1u) : 0u;
     // anchor of the fat ray at t = 0
     const float ax = gx - (m + m), ay = gy - (m + m);
     // start a few levels above the cells; lev = quadtree level of the current node (0 = cell)
@@ -270,47 +358,14 @@ __device__ __forceinline__ void trace_ray(const hf_dev_field &f, const hf_lds_mi
             // actual lower-left cell of the block (order column X+1 is the lower actual one when mirrored)
             const int c0 = fx ? ((1 << top) - 2 - (int) X) : (int) X;
             const int r0 = fy ? ((1 << top) - 2 - (int) Y) : (int) Y;
-            const int ca = min(max(c0, 0), f.W - 1), cb = min(max(c0 + 1, 0), f.W - 1), cc = min(max(c0 + 2, 0), f.W - 1);
-            const int ra = min(max(r0, 0), f.H - 1), rb = min(max(r0 + 1, 0), f.H - 1), rc = min(max(r0 + 2, 0), f.H - 1);
-            const float *p0 = f.h + (size_t) ra * f.W, *p1 = f.h + (size_t) rb * f.W, *p2 = f.h + (size_t) rc * f.W;
-            const float z00 = p0[ca] * f.s, z01 = p0[cb] * f.s, z02 = p0[cc] * f.s;
-            const float z10 = p1[ca] * f.s, z11 = p1[cb] * f.s, z12 = p1[cc] * f.s;
-            const float z20 = p2[ca] * f.s, z21 = p2[cb] * f.s, z22 = p2[cc] * f.s;
-            const bool vx0 = (c0 >= 0) & (c0 < cw), vx1 = (c0 + 1 >= 0) & (c0 + 1 < cw);
-            const bool vy0 = (r0 >= 0) & (r0 < ch), vy1 = (r0 + 1 >= 0) & (r0 + 1 < ch);
-            const float inf = __builtin_inff();
-            hf_quad q;
-            q.lo[0] = (vx0 & vy0) ? fminf(fminf(z00, z01), fminf(z10, z11)) : inf;
-            q.hi[0] = (vx0 & vy0) ? fmaxf(fmaxf(z00, z01), fmaxf(z10, z11)) : -inf;
-            q.lo[1] = (vx1 & vy0) ? fminf(fminf(z01, z02), fminf(z11, z12)) : inf;
-            q.hi[1] = (vx1 & vy0) ? fmaxf(fmaxf(z01, z02), fmaxf(z11, z12)) : -inf;
-            q.lo[2] = (vx0 & vy1) ? fminf(fminf(z10, z11), fminf(z20, z21)) : inf;
-            q.hi[2] = (vx0 & vy1) ? fmaxf(fmaxf(z10, z11), fmaxf(z20, z21)) : -inf;
-            q.lo[3] = (vx1 & vy1) ? fminf(fminf(z11, z12), fminf(z21, z22)) : inf;
-            q.hi[3] = (vx1 & vy1) ? fmaxf(fmaxf(z11, z12), fmaxf(z21, z22)) : -inf;
-            float tent[4];
-            const uint32_t cm = child_mask(r, (float) X, (float) Y, 1.f, q, thi, tent);
-            bool hit_any = false;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if ((cm >> j) & 1u) {
-                    if (tent[j] <= thi) {
-                        const float a = (j == 0) ? z00 : (j == 1) ? z01 : (j == 2) ? z10 : z11;
-                        const float b = (j == 0) ? z01 : (j == 1) ? z02 : (j == 2) ? z11 : z12;
-                        const float c = (j == 0) ? z10 : (j == 1) ? z11 : (j == 2) ? z20 : z21;
-                        const float e = (j == 0) ? z11 : (j == 1) ? z12 : (j == 2) ? z21 : z22;
+            const float *hp = f.h;
+            const int Wv = f.W;
+            const bool hit_any = test_block(f, rs, r, c0, r0, (float) X, (float) Y, t_in, t_out, true, thi, best,
+                                            [hp, Wv](int i, int j) { return hp[(size_t) i * Wv + j]; }
 #ifdef HF_STATS
-                        ++n_cells;
+                                            , n_cells
 #endif
-                        if (test_cell(f, c0 + (j & 1), r0 + (j >> 1), a, b, c, e, oo, od, maxt, best)) {
-                            hit_any = true;
-                            float tb = best.t - tin;
-                            tb = tb + __builtin_fabsf(tb) * 1e-6f + 1e-30f;
-                            thi = fminf(thi, tb);
-                        }
-                    }
-                }
-            }
+            );
             if (ANY && hit_any) break;
             // every cell the fat ray touches before t_out has now been tested: a hit that
             // precedes t_out is final.  (thi already carries the hit plus its margin.)
@@ -327,6 +382,94 @@ __device__ __forceinline__ void trace_ray(const hf_dev_field &f, const hf_lds_mi
 #ifdef HF_STATS
     best.u = (float) n_expand + 1000.f * (float) n_leafp; best.v = (float) n_cells + 1000.f * (float) n_iter;
     if (!best.hit) { best.hit = true; best.t = -1.f; }
+#endif
+}
+
+// actual-child mask -> order-space child mask (bit k = bit (k ^ flip))
+__device__ __forceinline__ uint32_t to_order(uint32_t m, bool fx, bool fy) {
+    if (fx) m = ((m & 5u) << 1) | ((m >> 1) & 5u);
+    if (fy) m = ((m & 3u) << 2) | ((m >> 2) & 3u);
+    return m;
+}
+
+// Wave-coherent walk ("packet"): the 64 rays of the wave share ONE depth-first walk of the
+// quadtree.  Node coordinates, level, pending-children masks and the mask stack are wave-uniform
+// (SGPRs / scalar unit); each lane only tests its own fat ray against the four child boxes of
+// the current node, and a child is entered when ANY lane overlaps it (ballot).  Children are
+// visited front to back in the common order space, which requires equal direction signs in
+// the wave (checked by the caller).  Per-lane results equal the per-lane walk's: every node a
+// lane's ray overlaps is visited because all its ancestors overlap that ray too.
+template <bool ANY>
+__device__ __forceinline__ void walk_packet(const hf_dev_field &f, const hf_ray_state &rs, bool alive, bool fx,
+                                            bool fy, hf_hit &best) {
+    const hf_trav &r = rs.r;
+    const int top = f.top, cw = f.W - 1, ch = f.H - 1;
+    float thi = alive ? rs.thi : -1.f; // dead lanes overlap nothing
+    const uint32_t fxm = fx ? ((1u << top) - 1u) : 0u, fym = fy ? ((1u << top) - 1u) : 0u;
+    const float2 *__restrict__ mip = f.mip;
+    const float *__restrict__ hp = f.h;
+    const int Wv = f.W;
+    (void) cw; (void) ch;
+#ifdef HF_STATS
+    uint32_t n_expand = 0, n_leafp = 0, n_cells = 0, n_iter = 0;
+#endif
+    uint32_t X = 0, Y = 0, cur = 1u; // cur: order-space children of (X,Y,L) still to visit
+    int L = top + 1;                 // virtual node above the root whose only child (k = 0) is the root
+    uint64_t stk = 0;
+    for (;;) {
+        while (cur == 0u) { // node exhausted: pop
+            if (L > top) goto done;
+            cur = (uint32_t) stk & 15u; stk >>= 4;
+            X >>= 1; Y >>= 1; ++L;
+        }
+        const uint32_t k = (uint32_t) __builtin_ctz(cur);
+        cur &= cur - 1u;
+        const uint32_t cx = 2u * X + (k & 1u), cy = 2u * Y + (k >> 1); // child, level L-1
+        if (ANY && __ballot(thi >= 0.f) == 0ull) goto done;
+        if (L - 1 == 1) {
+            // level-1 node: its 2x2 cells, exact per-lane tests
+            const uint32_t ix = cx ^ (fxm >> 1), iy = cy ^ (fym >> 1);
+#ifdef HF_STATS
+            ++n_leafp;
+#endif
+            const bool hit_any = test_block(f, rs, r, (int) (2u * ix), (int) (2u * iy), (float) (2u * cx),
+                                            (float) (2u * cy), 0.f, 0.f, false, thi, best,
+                                            [hp, Wv](int i, int j) { return hp[(size_t) i * Wv + j]; }
+#ifdef HF_STATS
+                                            , n_cells
+#endif
+            );
+            if (ANY && hit_any) thi = -1.f;
+            continue;
+        }
+        // inner node (cx,cy) of level L-1 >= 2: fetch its four child boxes (level L-2), per-lane overlap
+        stk = (stk << 4) | (uint64_t) cur;
+        X = cx; Y = cy; --L;
+#ifdef HF_STATS
+        ++n_expand;
+#endif
+        {
+            const int lc = L - 1;                       // children level
+            const uint32_t kd = (uint32_t) (top - lc);  // their pyramid depth, pitch 2^kd
+            const uint32_t ix = X ^ (fxm >> L), iy = Y ^ (fym >> L);
+            const uint32_t base = hf_depth_off((int) kd) + ((2u * iy) << kd) + 2u * ix;
+            const float2 b0 = mip[base], b1 = mip[base + 1u], b2 = mip[base + (1u << kd)], b3 = mip[base + (1u << kd) + 1u];
+            hf_quad q;
+            q.lo[0] = b0.x; q.hi[0] = b0.y; q.lo[1] = b1.x; q.hi[1] = b1.y;
+            q.lo[2] = b2.x; q.hi[2] = b2.y; q.lo[3] = b3.x; q.hi[3] = b3.y;
+            const float S = (float) (1u << lc);
+            float tent[4];
+            const uint32_t ml = child_mask(r, (float) X * (S + S), (float) Y * (S + S), S, q, thi, tent);
+            uint32_t ma = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ma |= (__ballot((ml >> j) & 1u) != 0ull) ? (1u << j) : 0u;
+            cur = to_order(ma, fx, fy);
+        }
+    }
+done:;
+#ifdef HF_STATS
+    best.u = (float) n_expand + 1000.f * (float) n_leafp; best.v = (float) n_cells + 1000.f * (float) n_iter;
+    if (alive && !best.hit) { best.hit = true; best.t = -1.f; }
 #endif
 }
 
@@ -403,7 +546,23 @@ __global__ __launch_bounds__(HF_BLOCK) void hf_trace_kernel(hf_dev_field f, size
             hf_hit best;
             best.hit = false; best.t = __builtin_inff(); best.u = 0.f; best.v = 0.f; best.prim = 0u;
             const bool act = active ? (active[i] != 0) : true;
-            if (act) trace_ray<MODE == 1>(f, s, o, d, maxt, best);
+            hf_ray_state rs;
+            const bool alive = act && setup_ray(f, s.node[0], o, d, maxt, rs);
+            const uint64_t am = __ballot(alive);
+            if (am != 0ull) {
+                // coherent wave?  equal direction signs, entry points and directions close to the first live lane's
+                const int src = __builtin_ctzll(am);
+                const bool fx0 = __shfl((int) rs.fx, src) != 0, fy0 = __shfl((int) rs.fy, src) != 0;
+                const float gx0 = __shfl(rs.gx, src), gy0 = __shfl(rs.gy, src);
+                const float ux = rs.r.idy, uy = rs.r.idx; // direction ratio proxy: compare idx/idy cross products
+                const float ux0 = __shfl(ux, src), uy0 = __shfl(uy, src);
+                const bool near = (rs.fx == fx0) & (rs.fy == fy0) & (__builtin_fabsf(rs.gx - gx0) <= 32.f) &
+                                  (__builtin_fabsf(rs.gy - gy0) <= 32.f) &
+                                  (__builtin_fabsf(ux * uy0 - uy * ux0) <= 0.05f * __builtin_fabsf(ux * uy0));
+                const bool coherent = __ballot(alive && !near) == 0ull;
+                if (coherent) walk_packet<MODE == 1>(f, rs, alive, fx0, fy0, best);
+                else if (alive) walk_dda<MODE == 1>(f, s, rs, best);
+            }
             if (MODE == 1) {
                 hit_out[i] = best.hit ? 1 : 0;
             } else {
