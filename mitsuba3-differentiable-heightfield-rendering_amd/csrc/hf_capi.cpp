@@ -219,7 +219,7 @@ extern "C" int hf_bbox(hf_field_t *hf, float out[6]) {
     if (!hf || !out) return fail(HF_EINVAL, "hf_bbox: NULL argument");
     float zr[2];
     HF_HIP(hipEventSynchronize(hf->built));
-    HF_HIP(hipMemcpy(zr, hf->d_mip, sizeof(zr), hipMemcpyDeviceToHost));
+    HF_HIP(hipMemcpy(zr, hf->d_mip + 1, sizeof(zr), hipMemcpyDeviceToHost));
     const hf_dev_field &d = hf->dev;
     const float lo[3] = { fmaf(0.f, d.sx, -1.f), fmaf(0.f, d.sy, -1.f), zr[0] };
     const float hi[3] = { fmaf((float) (d.W - 1), d.sx, -1.f), fmaf((float) (d.H - 1), d.sy, -1.f), zr[1] };

@@ -67,8 +67,8 @@ __device__ __forceinline__ v3 xform_vec(const float *m, v3 v) {
 // Quadtree over 2^top x 2^top cells (top >= 1; cells beyond the grid do not exist).
 // A node of level l covers 2^l x 2^l cells.  Levels 1..top are stored COARSE-FIRST in one
 // padded array: depth k = top - l holds 2^k x 2^k nodes, row-major with pitch 2^k, at
-// offset (4^k - 1)/3 (so the root is entry 0 and the first 1365 entries -- depths 0..5 --
-// are what the traversal kernels stage in LDS).  Entries are DILATED: node (ix,iy) of level
+// offset (4^k - 1)/3 + 1 (entry 0 is padding, the root is entry 1; the first 1366 entries --
+// depths 0..5 -- are what the traversal kernels stage in LDS).  Entries are DILATED: node (ix,iy) of level
 // l bounds the heights of cells [ix*2^l - 1, (ix+1)*2^l] x [iy*2^l - 1, (iy+1)*2^l]
 // (one extra cell on every side), which is what lets the hierarchical DDA follow a single
 // anchor point of the fat ray.  Nodes without any existing cell hold (+inf, -inf).
@@ -76,7 +76,7 @@ struct hf_dev_field {
     const float *h;    // W*H heights, row-major
     const float2 *mip; // (4^top - 1)/3 nodes
     int32_t W, H;
-    int32_t top;  // max(ceil(log2(max(W-1,H-1))), 1); mip[0] is the global (min,max)
+    int32_t top;  // max(ceil(log2(max(W-1,H-1))), 1); mip[1] is the global (min,max)
     float s, sx, sy, iu, iv;
     int32_t flip;
     float to_world[12], to_object[12];
@@ -84,8 +84,9 @@ struct hf_dev_field {
 
 // number of existing nodes per row / column at level l
 __host__ __device__ __forceinline__ int hf_level_w(int cells, int l) { return (cells + (1 << l) - 1) >> l; }
-// offset of pyramid depth k: (4^k - 1)/3
-__host__ __device__ __forceinline__ uint32_t hf_depth_off(int k) { return 0x55555555u & ((1u << (2 * k)) - 1u); }
+// offset of pyramid depth k: (4^k - 1)/3 + 1 (entry 0 is padding so that every depth >= 1 starts
+// on an even index: the two children of a node that share a row are one aligned 16-byte load)
+__host__ __device__ __forceinline__ uint32_t hf_depth_off(int k) { return (0x55555555u & ((1u << (2 * k)) - 1u)) + 1u; }
 
 struct hf_hit {
     float t, u, v;

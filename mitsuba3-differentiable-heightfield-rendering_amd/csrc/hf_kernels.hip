@@ -21,7 +21,8 @@
 #include "hf_launch.h"
 
 #define HF_BLOCK 256
-#define HF_LDS_NODES 1365 // pyramid depths 0..5 (1+4+16+64+256+1024 nodes) staged in LDS
+#define HF_LDS_NODES 1366 // padding + pyramid depths 0..5 (1+4+16+64+256+1024 nodes) staged in LDS
+#define HF_SUBTREE_LEVEL 3 // packet walk hands nodes of this level (8x8 cells) to the per-lane walk (<= 3: LDS tile)
 
 // ---------------------------------------------------------------------------------
 // min/max mip pyramid (coarse-first, padded, dilated -- see hf_dev_field)
@@ -60,6 +61,7 @@ __global__ __launch_bounds__(HF_BLOCK) void hf_mip_reduce_kernel(const float2 *_
 
 void hf_launch_build_mips(const hf_dev_field &f, float2 *mip, hipStream_t stream) {
     const int top = f.top;
+    (void) hipMemsetAsync(mip, 0, sizeof(float2), stream); // padding entry
     for (int k = top - 1; k >= 0; --k) {
         const int n = 1 << (2 * k), grid = (n + HF_BLOCK - 1) / HF_BLOCK;
         if (k == top - 1)
@@ -318,7 +320,7 @@ __device__ __forceinline__ void walk_dda(const hf_dev_field &f, const hf_lds_mip
             if (lev > 0) {
                 const uint32_t ix = X ^ (fxm >> lev), iy = Y ^ (fym >> lev);
                 const uint32_t k = (uint32_t) (top - lev);
-                const uint32_t a = (0x55555555u & ((1u << (2u * k)) - 1u)) + (iy << k) + ix;
+                const uint32_t a = hf_depth_off((int) k) + (iy << k) + ix;
                 float2 mm;
                 if (a < HF_LDS_NODES) mm = s.node[a];
                 else                  mm = f.mip[a];
@@ -392,30 +394,209 @@ __device__ __forceinline__ uint32_t to_order(uint32_t m, bool fx, bool fy) {
     return m;
 }
 
-// Wave-coherent walk ("packet"): the 64 rays of the wave share ONE depth-first walk of the
-// quadtree.  Node coordinates, level, pending-children masks and the mask stack are wave-uniform
-// (SGPRs / scalar unit); each lane only tests its own fat ray against the four child boxes of
-// the current node, and a child is entered when ANY lane overlaps it (ballot).  Children are
-// visited front to back in the common order space, which requires equal direction signs in
-// the wave (checked by the caller).  Per-lane results equal the per-lane walk's: every node a
-// lane's ray overlaps is visited because all its ancestors overlap that ray too.
+// fetch the four child boxes of inner node (ix,iy) (ACTUAL coordinates) of level L >= 2
+__device__ __forceinline__ void load_children(const float2 *__restrict__ mip, int top, int L, uint32_t ix, uint32_t iy,
+                                              hf_quad &q) {
+    const uint32_t kd = (uint32_t) (top - (L - 1)); // depth of the children, pitch 2^kd
+    const uint32_t base = hf_depth_off((int) kd) + ((2u * iy) << kd) + 2u * ix; // even: 16-byte aligned pairs
+    const float4 a = *(const float4 *) (mip + base), b = *(const float4 *) (mip + base + (1u << kd));
+    q.lo[0] = a.x; q.hi[0] = a.y; q.lo[1] = a.z; q.hi[1] = a.w;
+    q.lo[2] = b.x; q.hi[2] = b.y; q.lo[3] = b.z; q.hi[3] = b.w;
+}
+
+// ---- data sources of the per-lane subtree walk -------------------------------------------
+// straight from global memory
+struct hf_src_global {
+    const float2 *__restrict__ mip;
+    const float *__restrict__ h;
+    int top, W;
+    __device__ __forceinline__ void children(int L, uint32_t ix, uint32_t iy, hf_quad &q) const {
+        load_children(mip, top, L, ix, iy, q);
+    }
+    __device__ __forceinline__ float height(int i, int j) const { return h[(size_t) i * W + j]; }
+};
+
+// LDS tile of one level-L0 node (L0 <= 3): its (2^L0+1)^2 heights and the mip entries of its
+// descendants of levels L0-1 .. 1, staged by the whole wave with one round of coalesced loads
+// ("cell slab + mip tile"); the per-lane walk below that node then never leaves LDS.
+#define HF_TILE_FLOATS 128 // 81 heights, pad, 2*(4+16) mip floats from index 82
+struct hf_src_tile {
+    const float *t;      // this wave's tile
+    int L0, P;           // subtree root level, height pitch 2^L0+1
+    int r_base, c_base;  // first global row / column of the tile
+    uint32_t ix0, iy0;   // actual coordinates of the root node
+    // mip floats start at 82 (8-byte aligned float2 reads); level 2 (if L0 == 3): 4 nodes, then level 1
+    __device__ __forceinline__ int mip_base(int l) const { return 82 + ((L0 == 3 && l == 1) ? 8 : 0); }
+    __device__ __forceinline__ void children(int L, uint32_t ix, uint32_t iy, hf_quad &q) const {
+        const int l = L - 1, wl = 1 << (L0 - l);                  // children level, local nodes per row
+        const int lx = (int) (2u * ix) - (int) (ix0 << (L0 - l)), ly = (int) (2u * iy) - (int) (iy0 << (L0 - l));
+        const float *b = t + mip_base(l) + 2 * (ly * wl + lx);
+        const float2 c0 = *(const float2 *) b, c1 = *(const float2 *) (b + 2);
+        const float2 c2 = *(const float2 *) (b + 2 * wl), c3 = *(const float2 *) (b + 2 * wl + 2);
+        q.lo[0] = c0.x; q.hi[0] = c0.y; q.lo[1] = c1.x; q.hi[1] = c1.y;
+        q.lo[2] = c2.x; q.hi[2] = c2.y; q.lo[3] = c3.x; q.hi[3] = c3.y;
+    }
+    __device__ __forceinline__ float height(int i, int j) const { return t[max(i - r_base, 0) * P + max(j - c_base, 0)]; }
+};
+
+// wave-cooperative fill of the tile for actual node (ix0,iy0) of level L0 (all 64 lanes call this)
+__device__ __forceinline__ void stage_tile(const hf_dev_field &f, float *t, int L0, uint32_t ix0, uint32_t iy0) {
+    const int lane = (int) (threadIdx.x & 63u);
+    const int P = (1 << L0) + 1, nh = P * P;
+    const int r_base = (int) (iy0 << L0), c_base = (int) (ix0 << L0);
+#pragma unroll
+    for (int rep = 0; rep < 2; ++rep) {
+        const int idx = lane + 64 * rep;
+        if (idx < nh) {
+            const int lr = (L0 == 3) ? idx / 9 : (L0 == 2) ? idx / 5 : (L0 == 1) ? idx / 3 : idx / 2;
+            const int lc = idx - lr * P;
+            const int gi = min(r_base + lr, f.H - 1), gj = min(c_base + lc, f.W - 1);
+            t[idx] = f.h[(size_t) gi * f.W + gj];
+        }
+    }
+    // descendants' mip entries: level L0-1 (2x2) then ... level 1
+    int lane0 = 0, fbase = 82;
+    for (int l = L0 - 1; l >= 1; --l) {
+        const int wl = 1 << (L0 - l), cnt = wl * wl;
+        const int k = lane - lane0;
+        if (k >= 0 && k < cnt) {
+            const int ly = k / wl, lx = k - ly * wl;
+            const uint32_t kd = (uint32_t) (f.top - l);
+            const uint32_t gx = (ix0 << (L0 - l)) + (uint32_t) lx, gy = (iy0 << (L0 - l)) + (uint32_t) ly;
+            const float2 v = f.mip[hf_depth_off((int) kd) + (gy << kd) + gx];
+            *(float2 *) (t + fbase + 2 * k) = v;
+        }
+        lane0 += cnt; fbase += 2 * cnt;
+    }
+}
+
+// Per-lane depth-first walk of the subtree rooted at order-space node (X0,Y0) of level L0 >= 1
+// (pending-children masks of the levels below L0 in a 4-bit-per-level register stack).
+template <bool ANY, typename Src>
+__device__ __forceinline__ bool walk_subtree(const hf_dev_field &f, const Src &src, const hf_ray_state &rs,
+                                             const hf_trav &r, bool fx, bool fy, uint32_t fxm, uint32_t fym,
+                                             uint32_t X0, uint32_t Y0, int L0, float &thi, hf_hit &best
+#ifdef HF_STATS
+                                             , uint32_t &n_expand, uint32_t &n_leafp, uint32_t &n_cells
+#endif
+) {
+    auto loadh = [&src](int i, int j) { return src.height(i, j); };
+    bool hit_any = false;
+    if (L0 == 1) {
+        const uint32_t ix = X0 ^ (fxm >> 1), iy = Y0 ^ (fym >> 1);
+#ifdef HF_STATS
+        ++n_leafp;
+#endif
+        return test_block(f, rs, r, (int) (2u * ix), (int) (2u * iy), (float) (2u * X0), (float) (2u * Y0), 0.f, 0.f,
+                          false, thi, best, loadh
+#ifdef HF_STATS
+                          , n_cells
+#endif
+        );
+    }
+    uint32_t X = X0, Y = Y0, cur, stk = 0;
+    int L = L0;
+    {
+        hf_quad q;
+        src.children(L, X ^ (fxm >> L), Y ^ (fym >> L), q);
+        const float S = (float) (1u << (L - 1));
+        float tent[4];
+        cur = to_order(child_mask(r, (float) X * (S + S), (float) Y * (S + S), S, q, thi, tent), fx, fy);
+#ifdef HF_STATS
+        ++n_expand;
+#endif
+    }
+    for (;;) {
+        while (cur == 0u && L < L0) { // node exhausted: pop
+            cur = stk & 15u; stk >>= 4;
+            X >>= 1; Y >>= 1; ++L;
+        }
+        if (cur == 0u) break;
+        const uint32_t k = (uint32_t) __builtin_ctz(cur);
+        cur &= cur - 1u;
+        const uint32_t cx = 2u * X + (k & 1u), cy = 2u * Y + (k >> 1);
+        const float S = (float) (1u << (L - 1));
+        // the mask may predate a hit: re-check the child's entry against the current t_hi
+        const float te = fmaxf(((float) cx * S - r.gxm) * r.idx, ((float) cy * S - r.gym) * r.idy);
+        if (te > thi) continue;
+        if (L == 2) { // child is a level-1 node: its 2x2 cells
+            const uint32_t ix = cx ^ (fxm >> 1), iy = cy ^ (fym >> 1);
+#ifdef HF_DEBUG_TILE
+            {
+                const int c0d = (int) (2u * ix), r0d = (int) (2u * iy);
+                for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) {
+                    const int rr = min(max(r0d + a, 0), f.H - 1), cc2 = min(max(c0d + b, 0), f.W - 1);
+                    if (src.height(rr, cc2) != f.h[(size_t) rr * f.W + cc2]) { best.hit = true; best.t = -7.f; best.prim = (uint32_t) (rr * 256 + cc2); best.u = (float) L0; best.v = (float) (X0 * 256 + Y0); return true; }
+                }
+            }
+#endif
+#ifdef HF_STATS
+            ++n_leafp;
+#endif
+            if (test_block(f, rs, r, (int) (2u * ix), (int) (2u * iy), (float) (2u * cx), (float) (2u * cy), 0.f, 0.f,
+                           false, thi, best, loadh
+#ifdef HF_STATS
+                           , n_cells
+#endif
+                           )) {
+                hit_any = true;
+                if (ANY) break;
+            }
+            continue;
+        }
+        stk = (stk << 4) | cur;
+        X = cx; Y = cy; --L;
+        hf_quad q;
+        src.children(L, X ^ (fxm >> L), Y ^ (fym >> L), q);
+        const float Sc = (float) (1u << (L - 1));
+        float tent[4];
+        cur = to_order(child_mask(r, (float) X * (Sc + Sc), (float) Y * (Sc + Sc), Sc, q, thi, tent), fx, fy);
+#ifdef HF_STATS
+        ++n_expand;
+#endif
+    }
+    return hit_any;
+}
+
+// Wave-coherent walk: the 64 rays of the wave share ONE depth-first walk of the upper
+// quadtree levels.  Node coordinates, level, pending-children masks and the mask stack are
+// wave-uniform (SGPRs / scalar unit); each lane only tests its own fat ray against the four
+// child boxes of the current node, and a child is entered when ANY lane overlaps it (ballot).
+// Nodes of level HF_SUBTREE_LEVEL -- about the footprint of one pixel's rays -- are handed
+// to the per-lane walk of every lane that overlaps them.  Children are visited front to back
+// in the common order space, which requires equal direction signs in the wave (checked by the
+// caller).  Per-lane results equal a purely per-lane walk's: every node a lane's ray overlaps
+// is visited because all its ancestors overlap that ray too.
+#ifdef HF_TIMING
+#define HF_T0(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
+#define HF_TACC(acc, v) acc += __builtin_amdgcn_s_memtime() - v
+#else
+#define HF_T0(v)
+#define HF_TACC(acc, v)
+#endif
+
 template <bool ANY>
-__device__ __forceinline__ void walk_packet(const hf_dev_field &f, const hf_ray_state &rs, bool alive, bool fx,
-                                            bool fy, hf_hit &best) {
+__device__ __forceinline__ void walk_packet(const hf_dev_field &f, const hf_lds_mips &s, float *tile,
+                                            const hf_ray_state &rs, bool alive, bool fx, bool fy, hf_hit &best) {
     const hf_trav &r = rs.r;
-    const int top = f.top, cw = f.W - 1, ch = f.H - 1;
+    const int top = f.top;
     float thi = alive ? rs.thi : -1.f; // dead lanes overlap nothing
     const uint32_t fxm = fx ? ((1u << top) - 1u) : 0u, fym = fy ? ((1u << top) - 1u) : 0u;
     const float2 *__restrict__ mip = f.mip;
-    const float *__restrict__ hp = f.h;
-    const int Wv = f.W;
-    (void) cw; (void) ch;
 #ifdef HF_STATS
     uint32_t n_expand = 0, n_leafp = 0, n_cells = 0, n_iter = 0;
 #endif
     uint32_t X = 0, Y = 0, cur = 1u; // cur: order-space children of (X,Y,L) still to visit
     int L = top + 1;                 // virtual node above the root whose only child (k = 0) is the root
     uint64_t stk = 0;
+    uint32_t ml = alive ? 1u : 0u;   // per-lane overlap mask (ACTUAL child numbering) of the current node
+#ifdef HF_TIMING
+    unsigned long long t_sub = 0, t_all = 0;
+    HF_T0(tw0);
+#endif
+#ifdef HF_TIMING2
+    unsigned long long t_ld = 0, t_mk = 0; uint32_t n_pe = 0;
+#endif
     for (;;) {
         while (cur == 0u) { // node exhausted: pop
             if (L > top) goto done;
@@ -426,47 +607,79 @@ __device__ __forceinline__ void walk_packet(const hf_dev_field &f, const hf_ray_
         cur &= cur - 1u;
         const uint32_t cx = 2u * X + (k & 1u), cy = 2u * Y + (k >> 1); // child, level L-1
         if (ANY && __ballot(thi >= 0.f) == 0ull) goto done;
-        if (L - 1 == 1) {
-            // level-1 node: its 2x2 cells, exact per-lane tests
-            const uint32_t ix = cx ^ (fxm >> 1), iy = cy ^ (fym >> 1);
+        if (L - 1 <= HF_SUBTREE_LEVEL) {
+            // hand the node to the lanes whose ray overlaps it
+            const uint32_t j = k ^ ((fx ? 1u : 0u) | (fy ? 2u : 0u));
+            const float S = (float) (1u << (L - 1));
+            const float te = fmaxf(((float) cx * S - r.gxm) * r.idx, ((float) cy * S - r.gym) * r.idy);
+            const bool mine = (L > top) ? (thi >= 0.f) : ((((ml >> j) & 1u) != 0u) & (te <= thi));
 #ifdef HF_STATS
-            ++n_leafp;
+            ++n_iter;
 #endif
-            const bool hit_any = test_block(f, rs, r, (int) (2u * ix), (int) (2u * iy), (float) (2u * cx),
-                                            (float) (2u * cy), 0.f, 0.f, false, thi, best,
-                                            [hp, Wv](int i, int j) { return hp[(size_t) i * Wv + j]; }
+            HF_T0(ts0);
+            if (__ballot(mine) == 0ull) continue;
+            const int L0 = L - 1;
+            const uint32_t tix = cx ^ (fxm >> L0), tiy = cy ^ (fym >> L0);
+            stage_tile(f, tile, L0, tix, tiy);
+            hf_src_tile src;
+            src.t = tile; src.L0 = L0; src.P = (1 << L0) + 1;
+            src.r_base = (int) (tiy << L0); src.c_base = (int) (tix << L0); src.ix0 = tix; src.iy0 = tiy;
+            if (mine) {
+                const bool h = walk_subtree<ANY>(f, src, rs, r, fx, fy, fxm, fym, cx, cy, L0, thi, best
 #ifdef HF_STATS
-                                            , n_cells
+                                                 , n_expand, n_leafp, n_cells
 #endif
-            );
-            if (ANY && hit_any) thi = -1.f;
+                );
+                if (ANY && h) thi = -1.f;
+            }
+            HF_TACC(t_sub, ts0);
             continue;
         }
-        // inner node (cx,cy) of level L-1 >= 2: fetch its four child boxes (level L-2), per-lane overlap
+        // inner node (cx,cy) of level L-1: fetch its four child boxes (uniform address), per-lane overlap
         stk = (stk << 4) | (uint64_t) cur;
         X = cx; Y = cy; --L;
-#ifdef HF_STATS
-        ++n_expand;
-#endif
         {
-            const int lc = L - 1;                       // children level
-            const uint32_t kd = (uint32_t) (top - lc);  // their pyramid depth, pitch 2^kd
-            const uint32_t ix = X ^ (fxm >> L), iy = Y ^ (fym >> L);
-            const uint32_t base = hf_depth_off((int) kd) + ((2u * iy) << kd) + 2u * ix;
-            const float2 b0 = mip[base], b1 = mip[base + 1u], b2 = mip[base + (1u << kd)], b3 = mip[base + (1u << kd) + 1u];
+#ifdef HF_TIMING2
+            const unsigned long long q0 = __builtin_amdgcn_s_memtime(); ++n_pe;
+#endif
             hf_quad q;
-            q.lo[0] = b0.x; q.hi[0] = b0.y; q.lo[1] = b1.x; q.hi[1] = b1.y;
-            q.lo[2] = b2.x; q.hi[2] = b2.y; q.lo[3] = b3.x; q.hi[3] = b3.y;
-            const float S = (float) (1u << lc);
+            {   // children boxes: from the LDS-staged top of the pyramid when they are in it
+                const uint32_t kd = (uint32_t) (top - (L - 1));
+                const uint32_t ix = X ^ (fxm >> L), iy = Y ^ (fym >> L);
+                const uint32_t base = hf_depth_off((int) kd) + ((2u * iy) << kd) + 2u * ix;
+                float2 b0, b1, b2, b3;
+                if (base + (1u << kd) + 1u < HF_LDS_NODES) {
+                    b0 = s.node[base]; b1 = s.node[base + 1u]; b2 = s.node[base + (1u << kd)]; b3 = s.node[base + (1u << kd) + 1u];
+                } else {
+                    b0 = mip[base]; b1 = mip[base + 1u]; b2 = mip[base + (1u << kd)]; b3 = mip[base + (1u << kd) + 1u];
+                }
+                q.lo[0] = b0.x; q.hi[0] = b0.y; q.lo[1] = b1.x; q.hi[1] = b1.y;
+                q.lo[2] = b2.x; q.hi[2] = b2.y; q.lo[3] = b3.x; q.hi[3] = b3.y;
+            }
+#ifdef HF_TIMING2
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            const unsigned long long q1 = __builtin_amdgcn_s_memtime(); t_ld += q1 - q0;
+#endif
+            const float S = (float) (1u << (L - 1));
             float tent[4];
-            const uint32_t ml = child_mask(r, (float) X * (S + S), (float) Y * (S + S), S, q, thi, tent);
+            ml = child_mask(r, (float) X * (S + S), (float) Y * (S + S), S, q, thi, tent);
             uint32_t ma = 0;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) ma |= (__ballot((ml >> j) & 1u) != 0ull) ? (1u << j) : 0u;
+            for (int jj = 0; jj < 4; ++jj) ma |= (__ballot((ml >> jj) & 1u) != 0ull) ? (1u << jj) : 0u;
             cur = to_order(ma, fx, fy);
+#ifdef HF_TIMING2
+            t_mk += __builtin_amdgcn_s_memtime() - q1;
+#endif
         }
     }
 done:;
+#ifdef HF_TIMING2
+    best.u = (float) t_ld; best.v = (float) t_mk; if (alive) { best.hit = true; best.t = (float) n_pe; }
+#endif
+#ifdef HF_TIMING
+    HF_TACC(t_all, tw0);
+    best.u = (float) t_all; best.v = (float) t_sub; if (alive && !best.hit) { best.hit = true; best.t = -1.f; }
+#endif
 #ifdef HF_STATS
     best.u = (float) n_expand + 1000.f * (float) n_leafp; best.v = (float) n_cells + 1000.f * (float) n_iter;
     if (alive && !best.hit) { best.hit = true; best.t = -1.f; }
@@ -528,8 +741,10 @@ __global__ __launch_bounds__(HF_BLOCK) void hf_trace_kernel(hf_dev_field f, size
                                                             uint8_t *__restrict__ hit_out, hf_si_dev sio,
                                                             uint32_t flags, unsigned long long *counter) {
     __shared__ hf_lds_mips s;
+    __shared__ __attribute__((aligned(16))) float s_tile[HF_BLOCK / 64][HF_TILE_FLOATS];
     stage_mips(f, s);
     const unsigned lane = threadIdx.x & 63u;
+    float *tile = s_tile[threadIdx.x >> 6];
     for (;;) {
         unsigned long long base = 0;
         if (lane == 0) base = atomicAdd(counter, (unsigned long long) HF_GRAB);
@@ -538,16 +753,20 @@ __global__ __launch_bounds__(HF_BLOCK) void hf_trace_kernel(hf_dev_field f, size
         if (base >= n) break;
 #pragma unroll 1
         for (unsigned sub = 0; sub < HF_GRAB; sub += 64) {
-            const size_t i = base + sub + lane;
-            if (i >= n) break;
+            // all 64 lanes stay in the loop body (the coherent walk stages LDS tiles cooperatively);
+            // lanes past the end of the wavefront re-read the last ray and store nothing
+            const size_t i_raw = base + sub + lane;
+            if (base + sub >= n) break; // wave-uniform
+            const bool valid = i_raw < n;
+            const size_t i = valid ? i_raw : n - 1;
             const v3 o = mk3(rays.o[0][i], rays.o[1][i], rays.o[2][i]);
             const v3 d = mk3(rays.d[0][i], rays.d[1][i], rays.d[2][i]);
             const float maxt = rays.maxt[i];
             hf_hit best;
             best.hit = false; best.t = __builtin_inff(); best.u = 0.f; best.v = 0.f; best.prim = 0u;
-            const bool act = active ? (active[i] != 0) : true;
+            const bool act = valid && (active ? (active[i] != 0) : true);
             hf_ray_state rs;
-            const bool alive = act && setup_ray(f, s.node[0], o, d, maxt, rs);
+            const bool alive = act && setup_ray(f, s.node[1], o, d, maxt, rs);
             const uint64_t am = __ballot(alive);
             if (am != 0ull) {
                 // coherent wave?  equal direction signs, entry points and directions close to the first live lane's
@@ -560,9 +779,10 @@ __global__ __launch_bounds__(HF_BLOCK) void hf_trace_kernel(hf_dev_field f, size
                                   (__builtin_fabsf(rs.gy - gy0) <= 32.f) &
                                   (__builtin_fabsf(ux * uy0 - uy * ux0) <= 0.05f * __builtin_fabsf(ux * uy0));
                 const bool coherent = __ballot(alive && !near) == 0ull;
-                if (coherent) walk_packet<MODE == 1>(f, rs, alive, fx0, fy0, best);
+                if (coherent) walk_packet<MODE == 1>(f, s, tile, rs, alive, fx0, fy0, best);
                 else if (alive) walk_dda<MODE == 1>(f, s, rs, best);
             }
+            if (!valid) continue;
             if (MODE == 1) {
                 hit_out[i] = best.hit ? 1 : 0;
             } else {

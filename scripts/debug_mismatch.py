@@ -1,6 +1,9 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),'tests'))
 import numpy as np, torch, hf_amd, common
+if os.environ.get('HF_LIB'):
+    from hf_amd import _capi, build
+    build.LIB_PATH = os.environ['HF_LIB']; _capi._build.LIB_PATH = os.environ['HF_LIB']
 from oracle import hf_oracle as O
 W,H,kind = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
 rng = np.random.default_rng(W * 1000 + H)
