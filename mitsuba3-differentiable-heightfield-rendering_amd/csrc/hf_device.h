@@ -68,10 +68,9 @@ __device__ __forceinline__ v3 xform_vec(const float *m, v3 v) {
 // A node of level l covers 2^l x 2^l cells.  Levels 1..top are stored COARSE-FIRST in one
 // padded array: depth k = top - l holds 2^k x 2^k nodes, row-major with pitch 2^k, at
 // offset (4^k - 1)/3 + 1 (entry 0 is padding, the root is entry 1; the first 1366 entries --
-// depths 0..5 -- are what the traversal kernels stage in LDS).  Entries are DILATED: node (ix,iy) of level
-// l bounds the heights of cells [ix*2^l - 1, (ix+1)*2^l] x [iy*2^l - 1, (iy+1)*2^l]
-// (one extra cell on every side), which is what lets the hierarchical DDA follow a single
-// anchor point of the fat ray.  Nodes without any existing cell hold (+inf, -inf).
+// depths 0..5 -- are what the traversal kernels stage in LDS).  Node (ix,iy) of level l holds
+// (min z, max z) over the vertices of its existing cells; nodes without any existing cell hold
+// (+inf, -inf) and fail every overlap test.
 struct hf_dev_field {
     const float *h;    // W*H heights, row-major
     const float2 *mip; // (4^top - 1)/3 nodes

@@ -11,33 +11,37 @@
 // Traversal = depth-first walk of the implicit quadtree over the cells, children in
 // front-to-back order (the grid is mirrored so the ray direction is non-negative on
 // both axes: "order space").  One visit of an inner node fetches the (min z, max z)
-// boxes of its 4 children (blocked mip layout) and keeps those the *fat* ray segment
-// [0,t_hi] overlaps; a level-1 node fetches its 3x3 heights and tests the triangles
-// of the overlapped cells.  Pending children live in a 4-bit-per-level mask stack in
-// one 64-bit register.  The visited set is a conservative superset of the cells the
-// ray can hit; the per-triangle test and the tie rule are order independent, so the
-// result equals the brute force's.
+// boxes of its 4 children and keeps those the *fat* ray segment [0,t_hi] overlaps; a
+// level-1 node fetches its 3x3 heights and tests the triangles of the overlapped
+// cells.  Pending children live in 4-bit-per-level mask stacks held in registers.
+// Coherent waves share the walk of the upper levels (wave-uniform, scalar unit) and
+// stage 32x32-cell tiles (heights + their mip entries) in LDS for the per-lane walk
+// below; incoherent waves walk per lane straight from global memory.  The visited set
+// is a conservative superset of the cells the ray can hit; the per-triangle test and
+// the tie rule are order independent, so the result equals the brute force's.
 #include "hf_device.h"
 #include "hf_launch.h"
 
 #define HF_BLOCK 256
 #define HF_LDS_NODES 1366 // padding + pyramid depths 0..5 (1+4+16+64+256+1024 nodes) staged in LDS
-#define HF_SUBTREE_LEVEL 3 // packet walk hands nodes of this level (8x8 cells) to the per-lane walk (<= 3: LDS tile)
+#define HF_SUBTREE_LEVEL 3 // the coherent walk hands nodes of this level (8x8 cells) to the per-lane walk
+#ifndef HF_USE_TILE
+#define HF_USE_TILE 0     // 1: stage the handed-off node (level <= 5) as an LDS tile (measured slower so far: VGPR pressure)
+#endif
 
 // ---------------------------------------------------------------------------------
-// min/max mip pyramid (coarse-first, padded, dilated -- see hf_dev_field)
+// min/max mip pyramid (coarse-first, padded -- see hf_dev_field)
 // ---------------------------------------------------------------------------------
-// level 1: node (ix,iy) bounds cells [2ix-1, 2ix+2] x [2iy-1, 2iy+2], i.e. vertices [2ix-1, 2ix+3]^2
+// level 1: node (ix,iy) bounds cells [2ix, 2ix+1] x [2iy, 2iy+1], i.e. vertices [2ix, 2ix+2]^2
 __global__ __launch_bounds__(HF_BLOCK) void hf_mip_level1_kernel(const float *__restrict__ h, int W, int H, float s,
                                                                 float2 *__restrict__ out, int sh) {
     const int idx = blockIdx.x * HF_BLOCK + threadIdx.x;
     if (idx >= (1 << (2 * sh))) return;
     const int iy = idx >> sh, ix = idx & ((1 << sh) - 1);
     float mn = __builtin_inff(), mx = -__builtin_inff();
-    // existing cells of the dilated region (a node just outside the grid still bounds the
-    // grid cells within one cell of it), then their vertices
-    const int ci0 = max(2 * iy - 1, 0), ci1 = min(2 * iy + 2, H - 2);
-    const int cj0 = max(2 * ix - 1, 0), cj1 = min(2 * ix + 2, W - 2);
+    // cells [2ix, 2ix+1] x [2iy, 2iy+1] that exist, then their vertices
+    const int ci0 = 2 * iy, ci1 = min(2 * iy + 1, H - 2);
+    const int cj0 = 2 * ix, cj1 = min(2 * ix + 1, W - 2);
     if (ci0 <= ci1 && cj0 <= cj1) {
         for (int i = ci0; i <= ci1 + 1; ++i)
             for (int j = cj0; j <= cj1 + 1; ++j) {
@@ -48,7 +52,7 @@ __global__ __launch_bounds__(HF_BLOCK) void hf_mip_level1_kernel(const float *__
     out[idx] = make_float2(mn, mx);
 }
 
-// depth k from depth k+1: 2x2 reduce (the union of the children's dilated regions is the parent's)
+// depth k from depth k+1: 2x2 reduce
 __global__ __launch_bounds__(HF_BLOCK) void hf_mip_reduce_kernel(const float2 *__restrict__ in, float2 *__restrict__ out,
                                                                 int sh) {
     const int idx = blockIdx.x * HF_BLOCK + threadIdx.x;
@@ -272,121 +276,6 @@ __device__ __forceinline__ bool test_block(const hf_dev_field &f, const hf_ray_s
     return hit_any;
 }
 
-// Hierarchical DDA (per-lane walk; used for waves whose rays are not coherent).
-// The walk follows the ANCHOR a(t) = p(t) - (2m,2m) of the fat ray
-// (p = ray point in order space, m = xy margin): while a(t) is in node (X,Y) of some depth,
-// the fat square p +- m lies inside that node dilated by < 1 cell, which is what the dilated
-// mip entry bounds; at cell level it lies inside the 2x2 cell block anchored at a's cell.
-// Steps tile the parameter axis in increasing t, so the walk may stop as soon as a hit
-// precedes the end of the current step.
-template <bool ANY>
-__device__ __forceinline__ void walk_dda(const hf_dev_field &f, const hf_lds_mips &s, const hf_ray_state &rs,
-                                         hf_hit &best) {
-    const hf_trav &r = rs.r;
-    const int top = f.top;
-    const bool fx = rs.fx, fy = rs.fy;
-    const float gx = rs.gx, gy = rs.gy, m = rs.m, Wp = (float) (1 << top);
-    float thi = rs.thi;
-    const uint32_t fxm = fx ? ((1u << top) - 1u) : 0u, fym = fy ? ((1u << top) - 1u) : 0u;
-    // anchor of the fat ray at t = 0
-    const float ax = gx - (m + m), ay = gy - (m + m);
-    // start a few levels above the cells; lev = quadtree level of the current node (0 = cell)
-    int lev = top > 4 ? 4 : top - 1;
-    if (lev < 0) lev = 0;
-    uint32_t X, Y;
-    {
-        const float is = 1.0f / (float) (1u << lev);
-        const float qx = fminf(fmaxf(ax * is, 0.f), Wp), qy = fminf(fmaxf(ay * is, 0.f), Wp);
-        X = (uint32_t) qx; Y = (uint32_t) qy; // floor of a non-negative value
-    }
-    float t_in = 0.f;
-#ifdef HF_STATS
-    uint32_t n_expand = 0, n_leafp = 0, n_cells = 0, n_iter = 0;
-#endif
-    for (;;) {
-        // ---- phase 1: mip steps until the anchor sits in a cell whose 2x2 block must be tested ----
-        bool have = false;
-        float t_out = 0.f;
-        for (;;) {
-#ifdef HF_STATS
-            ++n_iter;
-#endif
-            const uint32_t n = 1u << (top - lev); // nodes per row at this level
-            if (X >= n || Y >= n) break;          // walked off the (padded) grid
-            const float S = (float) (1u << lev);
-            const float tox = ((float) (X + 1u) * S - ax) * r.idx, toy = ((float) (Y + 1u) * S - ay) * r.idy;
-            t_out = fminf(tox, toy); // anchor leaves the node (NaN of 0*inf dropped)
-            bool overlap = true;
-            if (lev > 0) {
-                const uint32_t ix = X ^ (fxm >> lev), iy = Y ^ (fym >> lev);
-                const uint32_t k = (uint32_t) (top - lev);
-                const uint32_t a = hf_depth_off((int) k) + (iy << k) + ix;
-                float2 mm;
-                if (a < HF_LDS_NODES) mm = s.node[a];
-                else                  mm = f.mip[a];
-                const float te = fminf(t_out, thi);
-                const float za = __builtin_fmaf(t_in, r.dz, r.gz), zb = __builtin_fmaf(te, r.dz, r.gz);
-                overlap = (fminf(za, zb) - r.mz <= mm.y) & (fmaxf(za, zb) + r.mz >= mm.x);
-#ifdef HF_STATS
-                ++n_expand;
-#endif
-            }
-            if (overlap) {
-                if (lev == 0) { have = true; break; }
-                // descend into the child that holds the anchor at t_in
-                --lev;
-                const float Sc = (float) (1u << lev);
-                const float tmx = ((float) (2u * X + 1u) * Sc - ax) * r.idx, tmy = ((float) (2u * Y + 1u) * Sc - ay) * r.idy;
-                X = 2u * X + ((tmx <= t_in) ? 1u : 0u);
-                Y = 2u * Y + ((tmy <= t_in) ? 1u : 0u);
-                continue;
-            }
-            // skip this node: step to the neighbour the anchor enters and climb while aligned
-            if (!(t_out < thi)) { lev = -1; break; }
-            t_in = t_out;
-            int c;
-            if (tox <= toy) { ++X; c = __builtin_ctz(X | 0x80000000u); }
-            else            { ++Y; c = __builtin_ctz(Y | 0x80000000u); }
-            c = min(c, top - 1 - lev);
-            c = max(c, 0);
-            X >>= c; Y >>= c; lev += c;
-        }
-        if (!have) break;
-#ifdef HF_STATS
-        ++n_leafp;
-#endif
-        // ---- phase 2: the 2x2 cell block anchored at order-space cell (X,Y): 3x3 heights, triangles ----
-        {
-            // actual lower-left cell of the block (order column X+1 is the lower actual one when mirrored)
-            const int c0 = fx ? ((1 << top) - 2 - (int) X) : (int) X;
-            const int r0 = fy ? ((1 << top) - 2 - (int) Y) : (int) Y;
-            const float *hp = f.h;
-            const int Wv = f.W;
-            const bool hit_any = test_block(f, rs, r, c0, r0, (float) X, (float) Y, t_in, t_out, true, thi, best,
-                                            [hp, Wv](int i, int j) { return hp[(size_t) i * Wv + j]; }
-#ifdef HF_STATS
-                                            , n_cells
-#endif
-            );
-            if (ANY && hit_any) break;
-            // every cell the fat ray touches before t_out has now been tested: a hit that
-            // precedes t_out is final.  (thi already carries the hit plus its margin.)
-            if (!(t_out < thi)) break;
-            t_in = t_out;
-            const float tox = ((float) (X + 1u) - ax) * r.idx, toy = ((float) (Y + 1u) - ay) * r.idy;
-            int c;
-            if (tox <= toy) { ++X; c = __builtin_ctz(X | 0x80000000u); }
-            else            { ++Y; c = __builtin_ctz(Y | 0x80000000u); }
-            c = min(c, top - 1);
-            X >>= c; Y >>= c; lev = c;
-        }
-    }
-#ifdef HF_STATS
-    best.u = (float) n_expand + 1000.f * (float) n_leafp; best.v = (float) n_cells + 1000.f * (float) n_iter;
-    if (!best.hit) { best.hit = true; best.t = -1.f; }
-#endif
-}
-
 // actual-child mask -> order-space child mask (bit k = bit (k ^ flip))
 __device__ __forceinline__ uint32_t to_order(uint32_t m, bool fx, bool fy) {
     if (fx) m = ((m & 5u) << 1) | ((m >> 1) & 5u);
@@ -416,25 +305,28 @@ struct hf_src_global {
     __device__ __forceinline__ float height(int i, int j) const { return h[(size_t) i * W + j]; }
 };
 
-// LDS tile of one level-L0 node (L0 <= 3): its (2^L0+1)^2 heights and the mip entries of its
-// descendants of levels L0-1 .. 1, staged by the whole wave with one round of coalesced loads
-// ("cell slab + mip tile"); the per-lane walk below that node then never leaves LDS.
-#define HF_TILE_FLOATS 128 // 81 heights, pad, 2*(4+16) mip floats from index 82
+// LDS tile of one level-L0 node (L0 <= HF_SUBTREE_LEVEL): its (2^L0+1)^2 heights and the mip
+// entries of its descendants of levels L0-1 .. 1, staged by the whole wave with one burst of
+// coalesced loads ("cell slab + mip tile"); the per-lane walk below that node never leaves LDS.
+#define HF_TILE_HEIGHTS 1090 // 33*33 heights, rounded up to an even count (8-byte aligned float2 behind it)
+#define HF_TILE_FLOATS (HF_TILE_HEIGHTS + 2 * (4 + 16 + 64 + 256))
 struct hf_src_tile {
     const float *t;      // this wave's tile
     int L0, P;           // subtree root level, height pitch 2^L0+1
     int r_base, c_base;  // first global row / column of the tile
     uint32_t ix0, iy0;   // actual coordinates of the root node
-    // mip floats start at 82 (8-byte aligned float2 reads); level 2 (if L0 == 3): 4 nodes, then level 1
-    __device__ __forceinline__ int mip_base(int l) const { return 82 + ((L0 == 3 && l == 1) ? 8 : 0); }
+    // level l < L0 holds 4^(L0-l) nodes; levels are stored coarse-first behind the heights
+    static __device__ __forceinline__ int mip_base(int L0, int l) {
+        const int d = L0 - l; // >= 1: nodes of the coarser stored levels = (4^d - 4)/3
+        return HF_TILE_HEIGHTS + 2 * ((int) (0x55555555u & ((1u << (2 * d)) - 1u)) - 1);
+    }
     __device__ __forceinline__ void children(int L, uint32_t ix, uint32_t iy, hf_quad &q) const {
         const int l = L - 1, wl = 1 << (L0 - l);                  // children level, local nodes per row
         const int lx = (int) (2u * ix) - (int) (ix0 << (L0 - l)), ly = (int) (2u * iy) - (int) (iy0 << (L0 - l));
-        const float *b = t + mip_base(l) + 2 * (ly * wl + lx);
-        const float2 c0 = *(const float2 *) b, c1 = *(const float2 *) (b + 2);
-        const float2 c2 = *(const float2 *) (b + 2 * wl), c3 = *(const float2 *) (b + 2 * wl + 2);
-        q.lo[0] = c0.x; q.hi[0] = c0.y; q.lo[1] = c1.x; q.hi[1] = c1.y;
-        q.lo[2] = c2.x; q.hi[2] = c2.y; q.lo[3] = c3.x; q.hi[3] = c3.y;
+        const float *b = t + mip_base(L0, l) + 2 * (ly * wl + lx);
+        const float4 c01 = *(const float4 *) b, c23 = *(const float4 *) (b + 2 * wl); // lx even: 16-byte aligned
+        q.lo[0] = c01.x; q.hi[0] = c01.y; q.lo[1] = c01.z; q.hi[1] = c01.w;
+        q.lo[2] = c23.x; q.hi[2] = c23.y; q.lo[3] = c23.z; q.hi[3] = c23.w;
     }
     __device__ __forceinline__ float height(int i, int j) const { return t[max(i - r_base, 0) * P + max(j - c_base, 0)]; }
 };
@@ -444,29 +336,30 @@ __device__ __forceinline__ void stage_tile(const hf_dev_field &f, float *t, int 
     const int lane = (int) (threadIdx.x & 63u);
     const int P = (1 << L0) + 1, nh = P * P;
     const int r_base = (int) (iy0 << L0), c_base = (int) (ix0 << L0);
-#pragma unroll
-    for (int rep = 0; rep < 2; ++rep) {
-        const int idx = lane + 64 * rep;
-        if (idx < nh) {
-            const int lr = (L0 == 3) ? idx / 9 : (L0 == 2) ? idx / 5 : (L0 == 1) ? idx / 3 : idx / 2;
-            const int lc = idx - lr * P;
-            const int gi = min(r_base + lr, f.H - 1), gj = min(c_base + lc, f.W - 1);
-            t[idx] = f.h[(size_t) gi * f.W + gj];
+    for (int idx = lane; idx < nh; idx += 64) {
+        int lr;
+        switch (L0) { // division by a compile-time constant in every arm
+            case 5: lr = idx / 33; break;
+            case 4: lr = idx / 17; break;
+            case 3: lr = idx / 9; break;
+            case 2: lr = idx / 5; break;
+            case 1: lr = idx / 3; break;
+            default: lr = idx / 2; break;
         }
+        const int lc = idx - lr * P;
+        const int gi = min(r_base + lr, f.H - 1), gj = min(c_base + lc, f.W - 1);
+        t[idx] = f.h[(size_t) gi * f.W + gj];
     }
-    // descendants' mip entries: level L0-1 (2x2) then ... level 1
-    int lane0 = 0, fbase = 82;
-    for (int l = L0 - 1; l >= 1; --l) {
-        const int wl = 1 << (L0 - l), cnt = wl * wl;
-        const int k = lane - lane0;
-        if (k >= 0 && k < cnt) {
-            const int ly = k / wl, lx = k - ly * wl;
-            const uint32_t kd = (uint32_t) (f.top - l);
-            const uint32_t gx = (ix0 << (L0 - l)) + (uint32_t) lx, gy = (iy0 << (L0 - l)) + (uint32_t) ly;
-            const float2 v = f.mip[hf_depth_off((int) kd) + (gy << kd) + gx];
-            *(float2 *) (t + fbase + 2 * k) = v;
+    for (int l = L0 - 1; l >= 1; --l) { // descendants' mip entries, coarse-first
+        const int sh = L0 - l, cnt = 1 << (2 * sh);
+        const uint32_t kd = (uint32_t) (f.top - l);
+        float *dst = t + hf_src_tile::mip_base(L0, l);
+        const float2 *srcl = f.mip + hf_depth_off((int) kd);
+        for (int k = lane; k < cnt; k += 64) {
+            const int ly = k >> sh, lx = k & ((1 << sh) - 1);
+            const uint32_t gx = (ix0 << sh) + (uint32_t) lx, gy = (iy0 << sh) + (uint32_t) ly;
+            *(float2 *) (dst + 2 * k) = srcl[(gy << kd) + gx];
         }
-        lane0 += cnt; fbase += 2 * cnt;
     }
 }
 
@@ -577,7 +470,8 @@ __device__ __forceinline__ bool walk_subtree(const hf_dev_field &f, const Src &s
 
 template <bool ANY>
 __device__ __forceinline__ void walk_packet(const hf_dev_field &f, const hf_lds_mips &s, float *tile,
-                                            const hf_ray_state &rs, bool alive, bool fx, bool fy, hf_hit &best) {
+                                            const hf_ray_state &rs, bool alive, bool coherent, bool fx, bool fy,
+                                            hf_hit &best) {
     const hf_trav &r = rs.r;
     const int top = f.top;
     float thi = alive ? rs.thi : -1.f; // dead lanes overlap nothing
@@ -607,8 +501,8 @@ __device__ __forceinline__ void walk_packet(const hf_dev_field &f, const hf_lds_
         cur &= cur - 1u;
         const uint32_t cx = 2u * X + (k & 1u), cy = 2u * Y + (k >> 1); // child, level L-1
         if (ANY && __ballot(thi >= 0.f) == 0ull) goto done;
-        if (L - 1 <= HF_SUBTREE_LEVEL) {
-            // hand the node to the lanes whose ray overlaps it
+        if (L - 1 <= (coherent ? HF_SUBTREE_LEVEL : top)) {
+            // hand the node to the lanes whose ray overlaps it (incoherent wave: the root, to every live lane)
             const uint32_t j = k ^ ((fx ? 1u : 0u) | (fy ? 2u : 0u));
             const float S = (float) (1u << (L - 1));
             const float te = fmaxf(((float) cx * S - r.gxm) * r.idx, ((float) cy * S - r.gym) * r.idy);
@@ -619,13 +513,20 @@ __device__ __forceinline__ void walk_packet(const hf_dev_field &f, const hf_lds_
             HF_T0(ts0);
             if (__ballot(mine) == 0ull) continue;
             const int L0 = L - 1;
+#if HF_USE_TILE
             const uint32_t tix = cx ^ (fxm >> L0), tiy = cy ^ (fym >> L0);
             stage_tile(f, tile, L0, tix, tiy);
             hf_src_tile src;
             src.t = tile; src.L0 = L0; src.P = (1 << L0) + 1;
             src.r_base = (int) (tiy << L0); src.c_base = (int) (tix << L0); src.ix0 = tix; src.iy0 = tiy;
+#else
+            hf_src_global src;
+            src.mip = f.mip; src.h = f.h; src.top = f.top; src.W = f.W;
+#endif
             if (mine) {
-                const bool h = walk_subtree<ANY>(f, src, rs, r, fx, fy, fxm, fym, cx, cy, L0, thi, best
+                // per-lane mirror flags: equal to (fx,fy) in a coherent wave, arbitrary otherwise
+                const uint32_t lfxm = rs.fx ? ((1u << top) - 1u) : 0u, lfym = rs.fy ? ((1u << top) - 1u) : 0u;
+                const bool h = walk_subtree<ANY>(f, src, rs, r, rs.fx, rs.fy, lfxm, lfym, cx, cy, L0, thi, best
 #ifdef HF_STATS
                                                  , n_expand, n_leafp, n_cells
 #endif
@@ -741,10 +642,14 @@ __global__ __launch_bounds__(HF_BLOCK) void hf_trace_kernel(hf_dev_field f, size
                                                             uint8_t *__restrict__ hit_out, hf_si_dev sio,
                                                             uint32_t flags, unsigned long long *counter) {
     __shared__ hf_lds_mips s;
+#if HF_USE_TILE
     __shared__ __attribute__((aligned(16))) float s_tile[HF_BLOCK / 64][HF_TILE_FLOATS];
+    float *tile = s_tile[threadIdx.x >> 6];
+#else
+    float *tile = nullptr;
+#endif
     stage_mips(f, s);
     const unsigned lane = threadIdx.x & 63u;
-    float *tile = s_tile[threadIdx.x >> 6];
     for (;;) {
         unsigned long long base = 0;
         if (lane == 0) base = atomicAdd(counter, (unsigned long long) HF_GRAB);
@@ -779,8 +684,8 @@ __global__ __launch_bounds__(HF_BLOCK) void hf_trace_kernel(hf_dev_field f, size
                                   (__builtin_fabsf(rs.gy - gy0) <= 32.f) &
                                   (__builtin_fabsf(ux * uy0 - uy * ux0) <= 0.05f * __builtin_fabsf(ux * uy0));
                 const bool coherent = __ballot(alive && !near) == 0ull;
-                if (coherent) walk_packet<MODE == 1>(f, s, tile, rs, alive, fx0, fy0, best);
-                else if (alive) walk_dda<MODE == 1>(f, s, rs, best);
+                // incoherent wave: the shared walk degenerates to handing the root to every live lane
+                walk_packet<MODE == 1>(f, s, tile, rs, alive, coherent, fx0, fy0, best);
             }
             if (!valid) continue;
             if (MODE == 1) {
