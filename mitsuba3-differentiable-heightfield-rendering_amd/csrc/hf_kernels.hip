@@ -637,7 +637,7 @@ __device__ __forceinline__ void miss_si(hf_si_rec &si, v3 d, uint32_t flags) {
 // counter (zeroed on the stream before the launch), so expensive image regions are
 // spread over all CUs whatever their position in the wavefront.
 template <int MODE>
-__global__ __launch_bounds__(HF_BLOCK) void hf_trace_kernel(hf_dev_field f, size_t n, hf_rays_dev rays,
+__global__ __launch_bounds__(HF_BLOCK, 4) void hf_trace_kernel(hf_dev_field f, size_t n, hf_rays_dev rays,
                                                             const uint8_t *__restrict__ active, hf_pi_dev pi,
                                                             uint8_t *__restrict__ hit_out, hf_si_dev sio,
                                                             uint32_t flags, unsigned long long *counter) {
@@ -743,7 +743,7 @@ void hf_launch_trace(int mode, const hf_dev_field &f, size_t n, const hf_rays_t 
     if (si) sd = to_dev(si);
     const hf_rays_dev r = to_dev(rays);
     size_t waves = (n + HF_GRAB - 1) / HF_GRAB, blocks = (waves + 3) / 4;
-    if (blocks > 256 * 6) blocks = 256 * 6;
+    if (blocks > 256 * 4) blocks = 256 * 4; // 4 resident workgroups per CU (128 VGPRs)
     const dim3 grid((unsigned) blocks), block(HF_BLOCK);
     if (mode == 0)
         hipLaunchKernelGGL(hf_trace_kernel<0>, grid, block, 0, stream, f, n, r, active, p, hit, sd, flags, counter);
