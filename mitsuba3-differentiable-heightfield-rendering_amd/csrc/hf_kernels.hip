@@ -211,17 +211,12 @@ __device__ __forceinline__ bool setup_ray(const hf_dev_field &f, float2 zr, v3 o
     return true;
 }
 
-// 3x3 heights -> the 2x2 cells of a block as boxes, exact fat-ray test per cell, triangles.
-// (c0,r0) = actual lower-left cell of the block, (fX,fY) = its order-space origin.
-// Returns true if any triangle was hit; best/thi are updated.
+// 3x3 heights -> the 2x2 cells of a block as exact boxes -> mask (ACTUAL numbering j = 2*jy+jx)
+// of the cells the fat ray can hit.  (c0,r0) = actual lower-left cell of the block, (fX,fY) = its
+// order-space origin.  The triangles themselves are tested later, wave-converged (walk_subtree).
 template <typename LoadH>
-__device__ __forceinline__ bool test_block(const hf_dev_field &f, const hf_ray_state &rs, const hf_trav &r, int c0,
-                                           int r0, float fX, float fY, float t_in, float t_out, bool prereject,
-                                           float &thi, hf_hit &best, LoadH loadh
-#ifdef HF_STATS
-                                           , uint32_t &n_cells
-#endif
-) {
+__device__ __forceinline__ uint32_t block_cells(const hf_dev_field &f, const hf_trav &r, int c0, int r0, float fX,
+                                                float fY, float thi, LoadH loadh) {
     const int cw = f.W - 1, ch = f.H - 1;
     const int ca = min(max(c0, 0), f.W - 1), cb = min(max(c0 + 1, 0), f.W - 1), cc = min(max(c0 + 2, 0), f.W - 1);
     const int ra = min(max(r0, 0), f.H - 1), rb = min(max(r0 + 1, 0), f.H - 1), rc = min(max(r0 + 2, 0), f.H - 1);
@@ -231,49 +226,17 @@ __device__ __forceinline__ bool test_block(const hf_dev_field &f, const hf_ray_s
     const bool vx0 = (c0 >= 0) & (c0 < cw), vx1 = (c0 + 1 >= 0) & (c0 + 1 < cw);
     const bool vy0 = (r0 >= 0) & (r0 < ch), vy1 = (r0 + 1 >= 0) & (r0 + 1 < ch);
     const float inf = __builtin_inff();
-    uint32_t cm = 0;
-    float tent[4] = { 0.f, 0.f, 0.f, 0.f };
-    bool go = true;
-    if (prereject) { // ray z over this step vs the bounds of all 9 heights
-        const float lo9 = fminf(fminf(fminf(fminf(z00, z01), fminf(z02, z10)), fminf(fminf(z11, z12), fminf(z20, z21))), z22);
-        const float hi9 = fmaxf(fmaxf(fmaxf(fmaxf(z00, z01), fmaxf(z02, z10)), fmaxf(fmaxf(z11, z12), fmaxf(z20, z21))), z22);
-        const float te = fminf(t_out, thi);
-        const float za = __builtin_fmaf(t_in, r.dz, r.gz), zb = __builtin_fmaf(te, r.dz, r.gz);
-        go = (fminf(za, zb) - r.mz <= hi9) & (fmaxf(za, zb) + r.mz >= lo9);
-    }
-    if (go) {
-        hf_quad q;
-        q.lo[0] = (vx0 & vy0) ? fminf(fminf(z00, z01), fminf(z10, z11)) : inf;
-        q.hi[0] = (vx0 & vy0) ? fmaxf(fmaxf(z00, z01), fmaxf(z10, z11)) : -inf;
-        q.lo[1] = (vx1 & vy0) ? fminf(fminf(z01, z02), fminf(z11, z12)) : inf;
-        q.hi[1] = (vx1 & vy0) ? fmaxf(fmaxf(z01, z02), fmaxf(z11, z12)) : -inf;
-        q.lo[2] = (vx0 & vy1) ? fminf(fminf(z10, z11), fminf(z20, z21)) : inf;
-        q.hi[2] = (vx0 & vy1) ? fmaxf(fmaxf(z10, z11), fmaxf(z20, z21)) : -inf;
-        q.lo[3] = (vx1 & vy1) ? fminf(fminf(z11, z12), fminf(z21, z22)) : inf;
-        q.hi[3] = (vx1 & vy1) ? fmaxf(fmaxf(z11, z12), fmaxf(z21, z22)) : -inf;
-        cm = child_mask(r, fX, fY, 1.f, q, thi, tent);
-    }
-    bool hit_any = false;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        if (__ballot(((cm >> j) & 1u) && tent[j] <= thi) == 0ull) continue; // no lane of the wave needs cell j
-        if (((cm >> j) & 1u) && tent[j] <= thi) {
-            const float a = (j == 0) ? z00 : (j == 1) ? z01 : (j == 2) ? z10 : z11;
-            const float b = (j == 0) ? z01 : (j == 1) ? z02 : (j == 2) ? z11 : z12;
-            const float c = (j == 0) ? z10 : (j == 1) ? z11 : (j == 2) ? z20 : z21;
-            const float e = (j == 0) ? z11 : (j == 1) ? z12 : (j == 2) ? z21 : z22;
-#ifdef HF_STATS
-            ++n_cells;
-#endif
-            if (test_cell(f, c0 + (j & 1), r0 + (j >> 1), a, b, c, e, rs.oo, rs.od, rs.maxt, best)) {
-                hit_any = true;
-                float tb = best.t - rs.tin;
-                tb = tb + __builtin_fabsf(tb) * 1e-6f + 1e-30f;
-                thi = fminf(thi, tb);
-            }
-        }
-    }
-    return hit_any;
+    hf_quad q;
+    q.lo[0] = (vx0 & vy0) ? fminf(fminf(z00, z01), fminf(z10, z11)) : inf;
+    q.hi[0] = (vx0 & vy0) ? fmaxf(fmaxf(z00, z01), fmaxf(z10, z11)) : -inf;
+    q.lo[1] = (vx1 & vy0) ? fminf(fminf(z01, z02), fminf(z11, z12)) : inf;
+    q.hi[1] = (vx1 & vy0) ? fmaxf(fmaxf(z01, z02), fmaxf(z11, z12)) : -inf;
+    q.lo[2] = (vx0 & vy1) ? fminf(fminf(z10, z11), fminf(z20, z21)) : inf;
+    q.hi[2] = (vx0 & vy1) ? fmaxf(fmaxf(z10, z11), fmaxf(z20, z21)) : -inf;
+    q.lo[3] = (vx1 & vy1) ? fminf(fminf(z11, z12), fminf(z21, z22)) : inf;
+    q.hi[3] = (vx1 & vy1) ? fmaxf(fmaxf(z11, z12), fmaxf(z21, z22)) : -inf;
+    float tent[4];
+    return child_mask(r, fX, fY, 1.f, q, thi, tent);
 }
 
 // actual-child mask -> order-space child mask (bit k = bit (k ^ flip))
@@ -365,6 +328,9 @@ __device__ __forceinline__ void stage_tile(const hf_dev_field &f, float *t, int 
 
 // Per-lane depth-first walk of the subtree rooted at order-space node (X0,Y0) of level L0 >= 1
 // (pending-children masks of the levels below L0 in a 4-bit-per-level register stack).
+// "while-while": each lane walks until it holds a block with candidate cells (or is done); when
+// every lane of the call has stopped, the candidate cells are triangle-tested together, one
+// cell per lane per round -- the expensive test runs with all waiting lanes active.
 template <bool ANY, typename Src>
 __device__ __forceinline__ bool walk_subtree(const hf_dev_field &f, const Src &src, const hf_ray_state &rs,
                                              const hf_trav &r, bool fx, bool fy, uint32_t fxm, uint32_t fym,
@@ -374,22 +340,20 @@ __device__ __forceinline__ bool walk_subtree(const hf_dev_field &f, const Src &s
 #endif
 ) {
     auto loadh = [&src](int i, int j) { return src.height(i, j); };
-    bool hit_any = false;
-    if (L0 == 1) {
-        const uint32_t ix = X0 ^ (fxm >> 1), iy = Y0 ^ (fym >> 1);
+#ifdef HF_TIMING3
+    unsigned long long tA = 0, tB = 0;
+#endif
+    bool hit_any = false, fin = false;
+    uint32_t X = X0, Y = Y0, cur = 0, stk = 0, pend = 0;
+    int L = L0, pc0 = 0, pr0 = 0;
+    if (L0 == 1) { // the root is itself a level-1 node: one block, no walk
+        pc0 = (int) (2u * (X0 ^ (fxm >> 1))); pr0 = (int) (2u * (Y0 ^ (fym >> 1)));
+        pend = block_cells(f, r, pc0, pr0, (float) (2u * X0), (float) (2u * Y0), thi, loadh);
+        fin = true;
 #ifdef HF_STATS
         ++n_leafp;
 #endif
-        return test_block(f, rs, r, (int) (2u * ix), (int) (2u * iy), (float) (2u * X0), (float) (2u * Y0), 0.f, 0.f,
-                          false, thi, best, loadh
-#ifdef HF_STATS
-                          , n_cells
-#endif
-        );
-    }
-    uint32_t X = X0, Y = Y0, cur, stk = 0;
-    int L = L0;
-    {
+    } else {
         hf_quad q;
         src.children(L, X ^ (fxm >> L), Y ^ (fym >> L), q);
         const float S = (float) (1u << (L - 1));
@@ -400,54 +364,73 @@ __device__ __forceinline__ bool walk_subtree(const hf_dev_field &f, const Src &s
 #endif
     }
     for (;;) {
-        while (cur == 0u && L < L0) { // node exhausted: pop
-            cur = stk & 15u; stk >>= 4;
-            X >>= 1; Y >>= 1; ++L;
+#ifdef HF_TIMING3
+        const unsigned long long a0 = __builtin_amdgcn_s_memtime();
+#endif
+        // ---- walk until this lane holds candidate cells or has exhausted the subtree ----
+        while (!fin && pend == 0u) {
+            while (cur == 0u && L < L0) { // node exhausted: pop
+                cur = stk & 15u; stk >>= 4;
+                X >>= 1; Y >>= 1; ++L;
+            }
+            if (cur == 0u) { fin = true; break; }
+            const uint32_t k = (uint32_t) __builtin_ctz(cur);
+            cur &= cur - 1u;
+            const uint32_t cx = 2u * X + (k & 1u), cy = 2u * Y + (k >> 1);
+            const float S = (float) (1u << (L - 1));
+            // the mask may predate a hit: re-check the child's entry against the current t_hi
+            const float te = fmaxf(((float) cx * S - r.gxm) * r.idx, ((float) cy * S - r.gym) * r.idy);
+            if (te > thi) continue;
+            if (L == 2) { // child is a level-1 node: its 2x2 cells
+                pc0 = (int) (2u * (cx ^ (fxm >> 1))); pr0 = (int) (2u * (cy ^ (fym >> 1)));
+                pend = block_cells(f, r, pc0, pr0, (float) (2u * cx), (float) (2u * cy), thi, loadh);
+#ifdef HF_STATS
+                ++n_leafp;
+#endif
+                continue;
+            }
+            stk = (stk << 4) | cur;
+            X = cx; Y = cy; --L;
+            hf_quad q;
+            src.children(L, X ^ (fxm >> L), Y ^ (fym >> L), q);
+            const float Sc = (float) (1u << (L - 1));
+            float tent[4];
+            cur = to_order(child_mask(r, (float) X * (Sc + Sc), (float) Y * (Sc + Sc), Sc, q, thi, tent), fx, fy);
+#ifdef HF_STATS
+            ++n_expand;
+#endif
         }
-        if (cur == 0u) break;
-        const uint32_t k = (uint32_t) __builtin_ctz(cur);
-        cur &= cur - 1u;
-        const uint32_t cx = 2u * X + (k & 1u), cy = 2u * Y + (k >> 1);
-        const float S = (float) (1u << (L - 1));
-        // the mask may predate a hit: re-check the child's entry against the current t_hi
-        const float te = fmaxf(((float) cx * S - r.gxm) * r.idx, ((float) cy * S - r.gym) * r.idy);
-        if (te > thi) continue;
-        if (L == 2) { // child is a level-1 node: its 2x2 cells
-            const uint32_t ix = cx ^ (fxm >> 1), iy = cy ^ (fym >> 1);
-#ifdef HF_DEBUG_TILE
-            {
-                const int c0d = (int) (2u * ix), r0d = (int) (2u * iy);
-                for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) {
-                    const int rr = min(max(r0d + a, 0), f.H - 1), cc2 = min(max(c0d + b, 0), f.W - 1);
-                    if (src.height(rr, cc2) != f.h[(size_t) rr * f.W + cc2]) { best.hit = true; best.t = -7.f; best.prim = (uint32_t) (rr * 256 + cc2); best.u = (float) L0; best.v = (float) (X0 * 256 + Y0); return true; }
+#ifdef HF_TIMING3
+        const unsigned long long a1 = __builtin_amdgcn_s_memtime(); tA += a1 - a0;
+#endif
+        if (__ballot(pend != 0u) == 0ull) break; // every lane is done
+        // ---- candidate cells, one per lane per round ----
+        while (__ballot(pend != 0u) != 0ull) {
+            if (pend != 0u) {
+                const int j = __builtin_ctz(pend);
+                pend &= pend - 1u;
+                const int cxx = pc0 + (j & 1), cyy = pr0 + (j >> 1);
+                const float z00 = loadh(cyy, cxx) * f.s, z10 = loadh(cyy, cxx + 1) * f.s;
+                const float z01 = loadh(cyy + 1, cxx) * f.s, z11 = loadh(cyy + 1, cxx + 1) * f.s;
+#ifdef HF_STATS
+                ++n_cells;
+#endif
+                if (test_cell(f, cxx, cyy, z00, z10, z01, z11, rs.oo, rs.od, rs.maxt, best)) {
+                    hit_any = true;
+                    float tb = best.t - rs.tin;
+                    tb = tb + __builtin_fabsf(tb) * 1e-6f + 1e-30f;
+                    thi = fminf(thi, tb);
+                    if (ANY) { pend = 0u; fin = true; }
                 }
             }
-#endif
-#ifdef HF_STATS
-            ++n_leafp;
-#endif
-            if (test_block(f, rs, r, (int) (2u * ix), (int) (2u * iy), (float) (2u * cx), (float) (2u * cy), 0.f, 0.f,
-                           false, thi, best, loadh
-#ifdef HF_STATS
-                           , n_cells
-#endif
-                           )) {
-                hit_any = true;
-                if (ANY) break;
-            }
-            continue;
         }
-        stk = (stk << 4) | cur;
-        X = cx; Y = cy; --L;
-        hf_quad q;
-        src.children(L, X ^ (fxm >> L), Y ^ (fym >> L), q);
-        const float Sc = (float) (1u << (L - 1));
-        float tent[4];
-        cur = to_order(child_mask(r, (float) X * (Sc + Sc), (float) Y * (Sc + Sc), Sc, q, thi, tent), fx, fy);
-#ifdef HF_STATS
-        ++n_expand;
+#ifdef HF_TIMING3
+        tB += __builtin_amdgcn_s_memtime() - a1;
 #endif
     }
+#ifdef HF_TIMING3
+    best.u += (float) tA; best.v += (float) tB;
+#endif
     return hit_any;
 }
 
@@ -487,6 +470,10 @@ __device__ __forceinline__ void walk_packet(const hf_dev_field &f, const hf_lds_
 #ifdef HF_TIMING
     unsigned long long t_sub = 0, t_all = 0;
     HF_T0(tw0);
+#endif
+#ifdef HF_TIMING3
+    best.u = 0.f; best.v = 0.f;
+    const unsigned long long w0 = __builtin_amdgcn_s_memtime();
 #endif
 #ifdef HF_TIMING2
     unsigned long long t_ld = 0, t_mk = 0; uint32_t n_pe = 0;
@@ -574,6 +561,9 @@ __device__ __forceinline__ void walk_packet(const hf_dev_field &f, const hf_lds_
         }
     }
 done:;
+#ifdef HF_TIMING3
+    if (alive) { best.hit = true; best.t = (float) (__builtin_amdgcn_s_memtime() - w0); }
+#endif
 #ifdef HF_TIMING2
     best.u = (float) t_ld; best.v = (float) t_mk; if (alive) { best.hit = true; best.t = (float) n_pe; }
 #endif
