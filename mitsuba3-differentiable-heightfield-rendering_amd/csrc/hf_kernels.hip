@@ -778,6 +778,8 @@ void hf_launch_si(const hf_dev_field &f, size_t n, const hf_rays_t *rays, const 
 // ---------------------------------------------------------------------------------
 // adjoint: reverse mode of compute_si, atomic scatter of dL/dheight
 // ---------------------------------------------------------------------------------
+#define HF_ADJ_TILE 32 // texels per side of the per-wave LDS accumulation tile
+
 struct hf_grad_dev {
     const float *t, *p[3], *n[3], *uv[2], *sh_n[3], *dp_du[3], *dp_dv[3];
 };
@@ -791,11 +793,26 @@ __global__ __launch_bounds__(HF_BLOCK) void hf_adjoint_kernel(hf_dev_field f, si
                                                               float *go2, float *gd0, float *gd1, float *gd2) {
     const bool follow = (flags & 0x80u) != 0, detach = (flags & 0x100u) != 0;
     const bool tex = (flags & (0x2u | 0x4u)) != 0;
+    // Wave-level pre-reduction of the scatter: the hits of one wave (one pixel's samples for
+    // primary rays) fall on a few dozen vertices, so their three contributions each are first
+    // summed into a 32x32-texel LDS tile anchored near the wave's first hit (ds_add_f32) and the
+    // tile is then flushed row by row -- contiguous segments, one global atomic per touched texel
+    // instead of three per ray.  Contributions outside the tile go straight to global memory.
+    __shared__ float s_acc[HF_BLOCK / 64][HF_ADJ_TILE * HF_ADJ_TILE];
+    float *acc = s_acc[threadIdx.x >> 6];
+    const int lane = (int) (threadIdx.x & 63u);
+    for (int k = lane; k < HF_ADJ_TILE * HF_ADJ_TILE; k += 64) acc[k] = 0.f;
     const size_t stride = (size_t) gridDim.x * HF_BLOCK;
-    for (size_t i = (size_t) blockIdx.x * HF_BLOCK + threadIdx.x; i < n; i += stride) {
+    const size_t n_round = (n + HF_BLOCK - 1) / HF_BLOCK * HF_BLOCK; // whole waves stay in the loop (ballots below)
+    for (size_t i_raw = (size_t) blockIdx.x * HF_BLOCK + threadIdx.x; i_raw < n_round; i_raw += stride) {
+        const bool valid = i_raw < n;
+        const size_t i = valid ? i_raw : n - 1;
         const float t_in = pi.t[i];
-        const bool act = (active ? (active[i] != 0) : true) && (t_in != __builtin_inff());
+        const bool act = valid && (active ? (active[i] != 0) : true) && (t_in != __builtin_inff());
         v3 go = mk3(0.f, 0.f, 0.f), gd = mk3(0.f, 0.f, 0.f);
+        float gh[3] = { 0.f, 0.f, 0.f };
+        int vr[3] = { 0, 0, 0 }, vc[3] = { 0, 0, 0 };
+        bool scatter = false;
         if (act) {
             const v3 o = mk3(rays.o[0][i], rays.o[1][i], rays.o[2][i]);
             const v3 d = mk3(rays.d[0][i], rays.d[1][i], rays.d[2][i]);
@@ -889,13 +906,42 @@ __global__ __launch_bounds__(HF_BLOCK) void hf_adjoint_kernel(hf_dev_field f, si
 
             if (!detach && grad_h) { // dP_k/dh_k = s * (third column of to_world)
                 const v3 ez = mk3(f.to_world[2], f.to_world[6], f.to_world[10]);
-                atomicAdd(grad_h + (size_t) vi[0] * f.W + vj[0], f.s * dot3(ez, gP0));
-                atomicAdd(grad_h + (size_t) vi[1] * f.W + vj[1], f.s * dot3(ez, gP1));
-                atomicAdd(grad_h + (size_t) vi[2] * f.W + vj[2], f.s * dot3(ez, gP2));
+                gh[0] = f.s * dot3(ez, gP0); gh[1] = f.s * dot3(ez, gP1); gh[2] = f.s * dot3(ez, gP2);
+                vr[0] = vi[0]; vr[1] = vi[1]; vr[2] = vi[2];
+                vc[0] = vj[0]; vc[1] = vj[1]; vc[2] = vj[2];
+                scatter = true;
             }
         }
-        if (go0) { go0[i] = go.x; go1[i] = go.y; go2[i] = go.z; }
-        if (gd0) { gd0[i] = gd.x; gd1[i] = gd.y; gd2[i] = gd.z; }
+        const uint64_t sm = __ballot(scatter);
+        if (sm != 0ull) {
+            // tile anchor from the first scattering lane (wave-uniform)
+            const int src = __builtin_ctzll(sm);
+            const int ar = __shfl(vr[0], src) - HF_ADJ_TILE / 4, ac = __shfl(vc[0], src) - HF_ADJ_TILE / 4;
+            if (scatter) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const int rr = vr[k] - ar, cc = vc[k] - ac;
+                    if ((unsigned) rr < (unsigned) HF_ADJ_TILE && (unsigned) cc < (unsigned) HF_ADJ_TILE)
+                        atomicAdd(acc + rr * HF_ADJ_TILE + cc, gh[k]);
+                    else
+                        atomicAdd(grad_h + (size_t) vr[k] * f.W + vc[k], gh[k]);
+                }
+            }
+            // flush: 64 consecutive tile entries (two 32-texel row segments) per wave-instruction
+            for (int k = lane; k < HF_ADJ_TILE * HF_ADJ_TILE; k += 64) {
+                const float v = acc[k];
+                if (__ballot(v != 0.f) == 0ull) continue;
+                if (v != 0.f) {
+                    const int rr = ar + k / HF_ADJ_TILE, cc = ac + k % HF_ADJ_TILE;
+                    atomicAdd(grad_h + (size_t) rr * f.W + cc, v);
+                    acc[k] = 0.f;
+                }
+            }
+        }
+        if (valid) {
+            if (go0) { go0[i] = go.x; go1[i] = go.y; go2[i] = go.z; }
+            if (gd0) { gd0[i] = gd.x; gd1[i] = gd.y; gd2[i] = gd.z; }
+        }
     }
 }
 
