@@ -12,19 +12,22 @@
 // front-to-back order (the grid is mirrored so the ray direction is non-negative on
 // both axes: "order space").  One visit of an inner node fetches the (min z, max z)
 // boxes of its 4 children and keeps those the *fat* ray segment [0,t_hi] overlaps; a
-// level-1 node fetches its 3x3 heights and tests the triangles of the overlapped
-// cells.  Pending children live in 4-bit-per-level mask stacks held in registers.
-// Coherent waves share the walk of the upper levels (wave-uniform, scalar unit) and
-// stage 32x32-cell tiles (heights + their mip entries) in LDS for the per-lane walk
-// below; incoherent waves walk per lane straight from global memory.  The visited set
-// is a conservative superset of the cells the ray can hit; the per-triangle test and
+// level-1 node fetches its 3x3 heights and yields the cells whose two triangles are
+// then tested.  Pending children live in 4-bit-per-level mask stacks held in registers.
+// The 64 rays of a coherent wave (primary rays: one pixel's samples) share the walk of
+// the upper levels -- node coordinates, masks and stack are wave-uniform and live in
+// SGPRs, a child is entered when __ballot says any lane overlaps it -- and nodes of
+// level HF_SUBTREE_LEVEL are handed to the per-lane walk; an incoherent wave hands the
+// root to every lane.  The per-lane walk is "while-while": lanes park on candidate cells
+// and the two-triangle test runs converged, one cell per lane per round.  The visited
+// set is a conservative superset of the cells the ray can hit; the per-triangle test and
 // the tie rule are order independent, so the result equals the brute force's.
 #include "hf_device.h"
 #include "hf_launch.h"
 
 #define HF_BLOCK 256
 #define HF_LDS_NODES 1366 // padding + pyramid depths 0..5 (1+4+16+64+256+1024 nodes) staged in LDS
-#define HF_SUBTREE_LEVEL 3 // the coherent walk hands nodes of this level (8x8 cells) to the per-lane walk
+#define HF_SUBTREE_LEVEL 5 // the coherent walk hands nodes of this level (8x8 cells) to the per-lane walk
 #ifndef HF_USE_TILE
 #define HF_USE_TILE 0     // 1: stage the handed-off node (level <= 5) as an LDS tile (measured slower so far: VGPR pressure)
 #endif
