@@ -94,6 +94,17 @@ __device__ __forceinline__ void stage_mips(const hf_dev_field &f, hf_lds_mips &s
     __syncthreads();
 }
 
+#ifdef HF_WSTATS
+// wave-level execution counters: WCOUNT(k) adds 1 per wave each time the enclosing code runs with any lane
+__device__ __forceinline__ uint32_t *wcnt_base() {
+    __shared__ uint32_t c[HF_BLOCK / 64][8];
+    return c[threadIdx.x >> 6];
+}
+#define WCOUNT(k) do { const uint64_t e_ = __ballot(true); if ((int) (threadIdx.x & 63u) == __builtin_ctzll(e_)) wcnt_base()[k]++; } while (0)
+#else
+#define WCOUNT(k) do { } while (0)
+#endif
+
 // per-ray traversal constants (order space, cell units, re-based at t = tin)
 struct hf_trav {
     float gxm, gxp, gym, gyp; // origin x,y  +/- the xy margin m
@@ -372,6 +383,7 @@ __device__ __forceinline__ bool walk_subtree(const hf_dev_field &f, const Src &s
 #endif
         // ---- walk until this lane holds candidate cells or has exhausted the subtree ----
         while (!fin && pend == 0u) {
+            WCOUNT(3);
             while (cur == 0u && L < L0) { // node exhausted: pop
                 cur = stk & 15u; stk >>= 4;
                 X >>= 1; Y >>= 1; ++L;
@@ -386,12 +398,14 @@ __device__ __forceinline__ bool walk_subtree(const hf_dev_field &f, const Src &s
             if (te > thi) continue;
             if (L == 2) { // child is a level-1 node: its 2x2 cells
                 pc0 = (int) (2u * (cx ^ (fxm >> 1))); pr0 = (int) (2u * (cy ^ (fym >> 1)));
+                WCOUNT(4);
                 pend = block_cells(f, r, pc0, pr0, (float) (2u * cx), (float) (2u * cy), thi, loadh);
 #ifdef HF_STATS
                 ++n_leafp;
 #endif
                 continue;
             }
+            WCOUNT(5);
             stk = (stk << 4) | cur;
             X = cx; Y = cy; --L;
             hf_quad q;
@@ -409,6 +423,7 @@ __device__ __forceinline__ bool walk_subtree(const hf_dev_field &f, const Src &s
         if (__ballot(pend != 0u) == 0ull) break; // every lane is done
         // ---- candidate cells, one per lane per round ----
         while (__ballot(pend != 0u) != 0ull) {
+            WCOUNT(6);
             if (pend != 0u) {
                 const int j = __builtin_ctz(pend);
                 pend &= pend - 1u;
@@ -470,6 +485,9 @@ __device__ __forceinline__ void walk_packet(const hf_dev_field &f, const hf_lds_
     int L = top + 1;                 // virtual node above the root whose only child (k = 0) is the root
     uint64_t stk = 0;
     uint32_t ml = alive ? 1u : 0u;   // per-lane overlap mask (ACTUAL child numbering) of the current node
+#ifdef HF_WSTATS
+    if ((threadIdx.x & 63u) < 8u) wcnt_base()[threadIdx.x & 63u] = 0u;
+#endif
 #ifdef HF_TIMING
     unsigned long long t_sub = 0, t_all = 0;
     HF_T0(tw0);
@@ -489,6 +507,7 @@ __device__ __forceinline__ void walk_packet(const hf_dev_field &f, const hf_lds_
         }
         const uint32_t k = (uint32_t) __builtin_ctz(cur);
         cur &= cur - 1u;
+        WCOUNT(1);
         const uint32_t cx = 2u * X + (k & 1u), cy = 2u * Y + (k >> 1); // child, level L-1
         if (ANY && __ballot(thi >= 0.f) == 0ull) goto done;
         if (L - 1 <= (coherent ? HF_SUBTREE_LEVEL : top)) {
@@ -502,6 +521,7 @@ __device__ __forceinline__ void walk_packet(const hf_dev_field &f, const hf_lds_
 #endif
             HF_T0(ts0);
             if (__ballot(mine) == 0ull) continue;
+            WCOUNT(2);
             const int L0 = L - 1;
 #if HF_USE_TILE
             const uint32_t tix = cx ^ (fxm >> L0), tiy = cy ^ (fym >> L0);
@@ -526,9 +546,17 @@ __device__ __forceinline__ void walk_packet(const hf_dev_field &f, const hf_lds_
             HF_TACC(t_sub, ts0);
             continue;
         }
-        // inner node (cx,cy) of level L-1: fetch its four child boxes (uniform address), per-lane overlap
+        // inner node (cx,cy) of level L-1.  Its mask bit may predate the hits found since: skip it when no
+        // lane can still reach it before its current t_hi
+        {
+            const float Sn = (float) (1u << (L - 1));
+            const float ten = fmaxf(((float) cx * Sn - r.gxm) * r.idx, ((float) cy * Sn - r.gym) * r.idy);
+            if (__ballot(ten <= thi) == 0ull) continue;
+        }
+        // fetch its four child boxes (uniform address), per-lane overlap
         stk = (stk << 4) | (uint64_t) cur;
         X = cx; Y = cy; --L;
+        WCOUNT(0);
         {
 #ifdef HF_TIMING2
             const unsigned long long q0 = __builtin_amdgcn_s_memtime(); ++n_pe;
@@ -564,6 +592,10 @@ __device__ __forceinline__ void walk_packet(const hf_dev_field &f, const hf_lds_
         }
     }
 done:;
+#ifdef HF_WSTATS
+    if (alive) { const uint32_t *c = wcnt_base(); best.hit = true; best.t = (float) c[0] + 1024.f * (float) c[1] + 1048576.f * (float) c[2];
+        best.u = (float) c[3] + 4096.f * (float) c[4]; best.v = (float) c[5] + 4096.f * (float) c[6]; }
+#endif
 #ifdef HF_TIMING3
     if (alive) { best.hit = true; best.t = (float) (__builtin_amdgcn_s_memtime() - w0); }
 #endif
