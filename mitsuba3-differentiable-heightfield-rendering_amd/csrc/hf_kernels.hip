@@ -357,16 +357,14 @@ __device__ __forceinline__ bool walk_subtree(const hf_dev_field &f, const Src &s
 #ifdef HF_TIMING3
     unsigned long long tA = 0, tB = 0;
 #endif
-    bool hit_any = false, fin = false;
+    bool hit_any = false, fin = false, pblk = false;
     uint32_t X = X0, Y = Y0, cur = 0, stk = 0, pend = 0;
     int L = L0, pc0 = 0, pr0 = 0;
+    float pfx = 0.f, pfy = 0.f; // order-space origin of the parked block
     if (L0 == 1) { // the root is itself a level-1 node: one block, no walk
         pc0 = (int) (2u * (X0 ^ (fxm >> 1))); pr0 = (int) (2u * (Y0 ^ (fym >> 1)));
-        pend = block_cells(f, r, pc0, pr0, (float) (2u * X0), (float) (2u * Y0), thi, loadh);
-        fin = true;
-#ifdef HF_STATS
-        ++n_leafp;
-#endif
+        pfx = (float) (2u * X0); pfy = (float) (2u * Y0);
+        pblk = true; fin = true;
     } else {
         hf_quad q;
         src.children(L, X ^ (fxm >> L), Y ^ (fym >> L), q);
@@ -378,11 +376,8 @@ __device__ __forceinline__ bool walk_subtree(const hf_dev_field &f, const Src &s
 #endif
     }
     for (;;) {
-#ifdef HF_TIMING3
-        const unsigned long long a0 = __builtin_amdgcn_s_memtime();
-#endif
-        // ---- walk until this lane holds candidate cells or has exhausted the subtree ----
-        while (!fin && pend == 0u) {
+        // ---- walk until this lane reaches a level-1 node (parks on it) or has exhausted the subtree ----
+        while (!fin && !pblk) {
             WCOUNT(3);
             while (cur == 0u && L < L0) { // node exhausted: pop
                 cur = stk & 15u; stk >>= 4;
@@ -396,13 +391,10 @@ __device__ __forceinline__ bool walk_subtree(const hf_dev_field &f, const Src &s
             // the mask may predate a hit: re-check the child's entry against the current t_hi
             const float te = fmaxf(((float) cx * S - r.gxm) * r.idx, ((float) cy * S - r.gym) * r.idy);
             if (te > thi) continue;
-            if (L == 2) { // child is a level-1 node: its 2x2 cells
+            if (L == 2) { // child is a level-1 node: park, its 2x2 cells are examined wave-converged below
                 pc0 = (int) (2u * (cx ^ (fxm >> 1))); pr0 = (int) (2u * (cy ^ (fym >> 1)));
-                WCOUNT(4);
-                pend = block_cells(f, r, pc0, pr0, (float) (2u * cx), (float) (2u * cy), thi, loadh);
-#ifdef HF_STATS
-                ++n_leafp;
-#endif
+                pfx = (float) (2u * cx); pfy = (float) (2u * cy);
+                pblk = true;
                 continue;
             }
             WCOUNT(5);
@@ -417,10 +409,16 @@ __device__ __forceinline__ bool walk_subtree(const hf_dev_field &f, const Src &s
             ++n_expand;
 #endif
         }
-#ifdef HF_TIMING3
-        const unsigned long long a1 = __builtin_amdgcn_s_memtime(); tA += a1 - a0;
+        if (__ballot(pblk) == 0ull) break; // every lane is done
+        // ---- parked blocks: 3x3 heights -> candidate cells, all parked lanes together ----
+        if (pblk) {
+            WCOUNT(4);
+            pend = block_cells(f, r, pc0, pr0, pfx, pfy, thi, loadh);
+            pblk = false;
+#ifdef HF_STATS
+            ++n_leafp;
 #endif
-        if (__ballot(pend != 0u) == 0ull) break; // every lane is done
+        }
         // ---- candidate cells, one per lane per round ----
         while (__ballot(pend != 0u) != 0ull) {
             WCOUNT(6);
