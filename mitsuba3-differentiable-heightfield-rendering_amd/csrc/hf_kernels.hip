@@ -27,10 +27,7 @@
 
 #define HF_BLOCK 256
 #define HF_LDS_NODES 1366 // padding + pyramid depths 0..5 (1+4+16+64+256+1024 nodes) staged in LDS
-#define HF_SUBTREE_LEVEL 5 // the coherent walk hands nodes of this level (8x8 cells) to the per-lane walk
-#ifndef HF_USE_TILE
-#define HF_USE_TILE 0     // 1: stage the handed-off node (level <= 5) as an LDS tile (measured slower so far: VGPR pressure)
-#endif
+#define HF_SUBTREE_LEVEL 5 // the shared walk hands nodes of this level (32x32 cells) to the per-lane walk
 
 // ---------------------------------------------------------------------------------
 // min/max mip pyramid (coarse-first, padded -- see hf_dev_field)
@@ -270,8 +267,7 @@ __device__ __forceinline__ void load_children(const float2 *__restrict__ mip, in
     q.lo[2] = b.x; q.hi[2] = b.y; q.lo[3] = b.z; q.hi[3] = b.w;
 }
 
-// ---- data sources of the per-lane subtree walk -------------------------------------------
-// straight from global memory
+// data source of the per-lane subtree walk: heights + mips straight from global memory (L1/L2)
 struct hf_src_global {
     const float2 *__restrict__ mip;
     const float *__restrict__ h;
@@ -282,64 +278,6 @@ struct hf_src_global {
     __device__ __forceinline__ float height(int i, int j) const { return h[(size_t) i * W + j]; }
 };
 
-// LDS tile of one level-L0 node (L0 <= HF_SUBTREE_LEVEL): its (2^L0+1)^2 heights and the mip
-// entries of its descendants of levels L0-1 .. 1, staged by the whole wave with one burst of
-// coalesced loads ("cell slab + mip tile"); the per-lane walk below that node never leaves LDS.
-#define HF_TILE_HEIGHTS 1090 // 33*33 heights, rounded up to an even count (8-byte aligned float2 behind it)
-#define HF_TILE_FLOATS (HF_TILE_HEIGHTS + 2 * (4 + 16 + 64 + 256))
-struct hf_src_tile {
-    const float *t;      // this wave's tile
-    int L0, P;           // subtree root level, height pitch 2^L0+1
-    int r_base, c_base;  // first global row / column of the tile
-    uint32_t ix0, iy0;   // actual coordinates of the root node
-    // level l < L0 holds 4^(L0-l) nodes; levels are stored coarse-first behind the heights
-    static __device__ __forceinline__ int mip_base(int L0, int l) {
-        const int d = L0 - l; // >= 1: nodes of the coarser stored levels = (4^d - 4)/3
-        return HF_TILE_HEIGHTS + 2 * ((int) (0x55555555u & ((1u << (2 * d)) - 1u)) - 1);
-    }
-    __device__ __forceinline__ void children(int L, uint32_t ix, uint32_t iy, hf_quad &q) const {
-        const int l = L - 1, wl = 1 << (L0 - l);                  // children level, local nodes per row
-        const int lx = (int) (2u * ix) - (int) (ix0 << (L0 - l)), ly = (int) (2u * iy) - (int) (iy0 << (L0 - l));
-        const float *b = t + mip_base(L0, l) + 2 * (ly * wl + lx);
-        const float4 c01 = *(const float4 *) b, c23 = *(const float4 *) (b + 2 * wl); // lx even: 16-byte aligned
-        q.lo[0] = c01.x; q.hi[0] = c01.y; q.lo[1] = c01.z; q.hi[1] = c01.w;
-        q.lo[2] = c23.x; q.hi[2] = c23.y; q.lo[3] = c23.z; q.hi[3] = c23.w;
-    }
-    __device__ __forceinline__ float height(int i, int j) const { return t[max(i - r_base, 0) * P + max(j - c_base, 0)]; }
-};
-
-// wave-cooperative fill of the tile for actual node (ix0,iy0) of level L0 (all 64 lanes call this)
-__device__ __forceinline__ void stage_tile(const hf_dev_field &f, float *t, int L0, uint32_t ix0, uint32_t iy0) {
-    const int lane = (int) (threadIdx.x & 63u);
-    const int P = (1 << L0) + 1, nh = P * P;
-    const int r_base = (int) (iy0 << L0), c_base = (int) (ix0 << L0);
-    for (int idx = lane; idx < nh; idx += 64) {
-        int lr;
-        switch (L0) { // division by a compile-time constant in every arm
-            case 5: lr = idx / 33; break;
-            case 4: lr = idx / 17; break;
-            case 3: lr = idx / 9; break;
-            case 2: lr = idx / 5; break;
-            case 1: lr = idx / 3; break;
-            default: lr = idx / 2; break;
-        }
-        const int lc = idx - lr * P;
-        const int gi = min(r_base + lr, f.H - 1), gj = min(c_base + lc, f.W - 1);
-        t[idx] = f.h[(size_t) gi * f.W + gj];
-    }
-    for (int l = L0 - 1; l >= 1; --l) { // descendants' mip entries, coarse-first
-        const int sh = L0 - l, cnt = 1 << (2 * sh);
-        const uint32_t kd = (uint32_t) (f.top - l);
-        float *dst = t + hf_src_tile::mip_base(L0, l);
-        const float2 *srcl = f.mip + hf_depth_off((int) kd);
-        for (int k = lane; k < cnt; k += 64) {
-            const int ly = k >> sh, lx = k & ((1 << sh) - 1);
-            const uint32_t gx = (ix0 << sh) + (uint32_t) lx, gy = (iy0 << sh) + (uint32_t) ly;
-            *(float2 *) (dst + 2 * k) = srcl[(gy << kd) + gx];
-        }
-    }
-}
-
 // Per-lane depth-first walk of the subtree rooted at order-space node (X0,Y0) of level L0 >= 1
 // (pending-children masks of the levels below L0 in a 4-bit-per-level register stack).
 // "while-while": each lane walks until it holds a block with candidate cells (or is done); when
@@ -349,14 +287,8 @@ template <bool ANY, typename Src>
 __device__ __forceinline__ bool walk_subtree(const hf_dev_field &f, const Src &src, const hf_ray_state &rs,
                                              const hf_trav &r, bool fx, bool fy, uint32_t fxm, uint32_t fym,
                                              uint32_t X0, uint32_t Y0, int L0, float &thi, hf_hit &best
-#ifdef HF_STATS
-                                             , uint32_t &n_expand, uint32_t &n_leafp, uint32_t &n_cells
-#endif
 ) {
     auto loadh = [&src](int i, int j) { return src.height(i, j); };
-#ifdef HF_TIMING3
-    unsigned long long tA = 0, tB = 0;
-#endif
     bool hit_any = false, fin = false, pblk = false;
     uint32_t X = X0, Y = Y0, cur = 0, stk = 0, pend = 0;
     int L = L0, pc0 = 0, pr0 = 0;
@@ -371,9 +303,6 @@ __device__ __forceinline__ bool walk_subtree(const hf_dev_field &f, const Src &s
         const float S = (float) (1u << (L - 1));
         float tent[4];
         cur = to_order(child_mask(r, (float) X * (S + S), (float) Y * (S + S), S, q, thi, tent), fx, fy);
-#ifdef HF_STATS
-        ++n_expand;
-#endif
     }
     for (;;) {
         // ---- walk until this lane reaches a level-1 node (parks on it) or has exhausted the subtree ----
@@ -405,9 +334,6 @@ __device__ __forceinline__ bool walk_subtree(const hf_dev_field &f, const Src &s
             const float Sc = (float) (1u << (L - 1));
             float tent[4];
             cur = to_order(child_mask(r, (float) X * (Sc + Sc), (float) Y * (Sc + Sc), Sc, q, thi, tent), fx, fy);
-#ifdef HF_STATS
-            ++n_expand;
-#endif
         }
         if (__ballot(pblk) == 0ull) break; // every lane is done
         // ---- parked blocks: 3x3 heights -> candidate cells, all parked lanes together ----
@@ -415,9 +341,6 @@ __device__ __forceinline__ bool walk_subtree(const hf_dev_field &f, const Src &s
             WCOUNT(4);
             pend = block_cells(f, r, pc0, pr0, pfx, pfy, thi, loadh);
             pblk = false;
-#ifdef HF_STATS
-            ++n_leafp;
-#endif
         }
         // ---- candidate cells, one per lane per round ----
         while (__ballot(pend != 0u) != 0ull) {
@@ -428,9 +351,6 @@ __device__ __forceinline__ bool walk_subtree(const hf_dev_field &f, const Src &s
                 const int cxx = pc0 + (j & 1), cyy = pr0 + (j >> 1);
                 const float z00 = loadh(cyy, cxx) * f.s, z10 = loadh(cyy, cxx + 1) * f.s;
                 const float z01 = loadh(cyy + 1, cxx) * f.s, z11 = loadh(cyy + 1, cxx + 1) * f.s;
-#ifdef HF_STATS
-                ++n_cells;
-#endif
                 if (test_cell(f, cxx, cyy, z00, z10, z01, z11, rs.oo, rs.od, rs.maxt, best)) {
                     hit_any = true;
                     float tb = best.t - rs.tin;
@@ -440,13 +360,7 @@ __device__ __forceinline__ bool walk_subtree(const hf_dev_field &f, const Src &s
                 }
             }
         }
-#ifdef HF_TIMING3
-        tB += __builtin_amdgcn_s_memtime() - a1;
-#endif
     }
-#ifdef HF_TIMING3
-    best.u += (float) tA; best.v += (float) tB;
-#endif
     return hit_any;
 }
 
@@ -459,16 +373,9 @@ __device__ __forceinline__ bool walk_subtree(const hf_dev_field &f, const Src &s
 // in the common order space, which requires equal direction signs in the wave (checked by the
 // caller).  Per-lane results equal a purely per-lane walk's: every node a lane's ray overlaps
 // is visited because all its ancestors overlap that ray too.
-#ifdef HF_TIMING
-#define HF_T0(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
-#define HF_TACC(acc, v) acc += __builtin_amdgcn_s_memtime() - v
-#else
-#define HF_T0(v)
-#define HF_TACC(acc, v)
-#endif
 
 template <bool ANY>
-__device__ __forceinline__ void walk_packet(const hf_dev_field &f, const hf_lds_mips &s, float *tile,
+__device__ __forceinline__ void walk_packet(const hf_dev_field &f, const hf_lds_mips &s,
                                             const hf_ray_state &rs, bool alive, bool coherent, bool fx, bool fy,
                                             hf_hit &best) {
     const hf_trav &r = rs.r;
@@ -476,26 +383,12 @@ __device__ __forceinline__ void walk_packet(const hf_dev_field &f, const hf_lds_
     float thi = alive ? rs.thi : -1.f; // dead lanes overlap nothing
     const uint32_t fxm = fx ? ((1u << top) - 1u) : 0u, fym = fy ? ((1u << top) - 1u) : 0u;
     const float2 *__restrict__ mip = f.mip;
-#ifdef HF_STATS
-    uint32_t n_expand = 0, n_leafp = 0, n_cells = 0, n_iter = 0;
-#endif
     uint32_t X = 0, Y = 0, cur = 1u; // cur: order-space children of (X,Y,L) still to visit
     int L = top + 1;                 // virtual node above the root whose only child (k = 0) is the root
     uint64_t stk = 0;
     uint32_t ml = alive ? 1u : 0u;   // per-lane overlap mask (ACTUAL child numbering) of the current node
 #ifdef HF_WSTATS
     if ((threadIdx.x & 63u) < 8u) wcnt_base()[threadIdx.x & 63u] = 0u;
-#endif
-#ifdef HF_TIMING
-    unsigned long long t_sub = 0, t_all = 0;
-    HF_T0(tw0);
-#endif
-#ifdef HF_TIMING3
-    best.u = 0.f; best.v = 0.f;
-    const unsigned long long w0 = __builtin_amdgcn_s_memtime();
-#endif
-#ifdef HF_TIMING2
-    unsigned long long t_ld = 0, t_mk = 0; uint32_t n_pe = 0;
 #endif
     for (;;) {
         while (cur == 0u) { // node exhausted: pop
@@ -514,34 +407,18 @@ __device__ __forceinline__ void walk_packet(const hf_dev_field &f, const hf_lds_
             const float S = (float) (1u << (L - 1));
             const float te = fmaxf(((float) cx * S - r.gxm) * r.idx, ((float) cy * S - r.gym) * r.idy);
             const bool mine = (L > top) ? (thi >= 0.f) : ((((ml >> j) & 1u) != 0u) & (te <= thi));
-#ifdef HF_STATS
-            ++n_iter;
-#endif
-            HF_T0(ts0);
             if (__ballot(mine) == 0ull) continue;
             WCOUNT(2);
             const int L0 = L - 1;
-#if HF_USE_TILE
-            const uint32_t tix = cx ^ (fxm >> L0), tiy = cy ^ (fym >> L0);
-            stage_tile(f, tile, L0, tix, tiy);
-            hf_src_tile src;
-            src.t = tile; src.L0 = L0; src.P = (1 << L0) + 1;
-            src.r_base = (int) (tiy << L0); src.c_base = (int) (tix << L0); src.ix0 = tix; src.iy0 = tiy;
-#else
             hf_src_global src;
             src.mip = f.mip; src.h = f.h; src.top = f.top; src.W = f.W;
-#endif
             if (mine) {
                 // per-lane mirror flags: equal to (fx,fy) in a coherent wave, arbitrary otherwise
                 const uint32_t lfxm = rs.fx ? ((1u << top) - 1u) : 0u, lfym = rs.fy ? ((1u << top) - 1u) : 0u;
                 const bool h = walk_subtree<ANY>(f, src, rs, r, rs.fx, rs.fy, lfxm, lfym, cx, cy, L0, thi, best
-#ifdef HF_STATS
-                                                 , n_expand, n_leafp, n_cells
-#endif
                 );
                 if (ANY && h) thi = -1.f;
             }
-            HF_TACC(t_sub, ts0);
             continue;
         }
         // inner node (cx,cy) of level L-1.  Its mask bit may predate the hits found since: skip it when no
@@ -556,9 +433,6 @@ __device__ __forceinline__ void walk_packet(const hf_dev_field &f, const hf_lds_
         X = cx; Y = cy; --L;
         WCOUNT(0);
         {
-#ifdef HF_TIMING2
-            const unsigned long long q0 = __builtin_amdgcn_s_memtime(); ++n_pe;
-#endif
             hf_quad q;
             {   // children boxes: from the LDS-staged top of the pyramid when they are in it
                 const uint32_t kd = (uint32_t) (top - (L - 1));
@@ -573,10 +447,6 @@ __device__ __forceinline__ void walk_packet(const hf_dev_field &f, const hf_lds_
                 q.lo[0] = b0.x; q.hi[0] = b0.y; q.lo[1] = b1.x; q.hi[1] = b1.y;
                 q.lo[2] = b2.x; q.hi[2] = b2.y; q.lo[3] = b3.x; q.hi[3] = b3.y;
             }
-#ifdef HF_TIMING2
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            const unsigned long long q1 = __builtin_amdgcn_s_memtime(); t_ld += q1 - q0;
-#endif
             const float S = (float) (1u << (L - 1));
             float tent[4];
             ml = child_mask(r, (float) X * (S + S), (float) Y * (S + S), S, q, thi, tent);
@@ -584,29 +454,12 @@ __device__ __forceinline__ void walk_packet(const hf_dev_field &f, const hf_lds_
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) ma |= (__ballot((ml >> jj) & 1u) != 0ull) ? (1u << jj) : 0u;
             cur = to_order(ma, fx, fy);
-#ifdef HF_TIMING2
-            t_mk += __builtin_amdgcn_s_memtime() - q1;
-#endif
         }
     }
 done:;
 #ifdef HF_WSTATS
     if (alive) { const uint32_t *c = wcnt_base(); best.hit = true; best.t = (float) c[0] + 1024.f * (float) c[1] + 1048576.f * (float) c[2];
         best.u = (float) c[3] + 4096.f * (float) c[4]; best.v = (float) c[5] + 4096.f * (float) c[6]; }
-#endif
-#ifdef HF_TIMING3
-    if (alive) { best.hit = true; best.t = (float) (__builtin_amdgcn_s_memtime() - w0); }
-#endif
-#ifdef HF_TIMING2
-    best.u = (float) t_ld; best.v = (float) t_mk; if (alive) { best.hit = true; best.t = (float) n_pe; }
-#endif
-#ifdef HF_TIMING
-    HF_TACC(t_all, tw0);
-    best.u = (float) t_all; best.v = (float) t_sub; if (alive && !best.hit) { best.hit = true; best.t = -1.f; }
-#endif
-#ifdef HF_STATS
-    best.u = (float) n_expand + 1000.f * (float) n_leafp; best.v = (float) n_cells + 1000.f * (float) n_iter;
-    if (alive && !best.hit) { best.hit = true; best.t = -1.f; }
 #endif
 }
 
@@ -665,12 +518,6 @@ __global__ __launch_bounds__(HF_BLOCK, 4) void hf_trace_kernel(hf_dev_field f, s
                                                             uint8_t *__restrict__ hit_out, hf_si_dev sio,
                                                             uint32_t flags, unsigned long long *counter) {
     __shared__ hf_lds_mips s;
-#if HF_USE_TILE
-    __shared__ __attribute__((aligned(16))) float s_tile[HF_BLOCK / 64][HF_TILE_FLOATS];
-    float *tile = s_tile[threadIdx.x >> 6];
-#else
-    float *tile = nullptr;
-#endif
     stage_mips(f, s);
     const unsigned lane = threadIdx.x & 63u;
     for (;;) {
@@ -681,7 +528,7 @@ __global__ __launch_bounds__(HF_BLOCK, 4) void hf_trace_kernel(hf_dev_field f, s
         if (base >= n) break;
 #pragma unroll 1
         for (unsigned sub = 0; sub < HF_GRAB; sub += 64) {
-            // all 64 lanes stay in the loop body (the coherent walk stages LDS tiles cooperatively);
+            // all 64 lanes stay in the loop body (the shared walk relies on whole-wave ballots);
             // lanes past the end of the wavefront re-read the last ray and store nothing
             const size_t i_raw = base + sub + lane;
             if (base + sub >= n) break; // wave-uniform
@@ -708,7 +555,7 @@ __global__ __launch_bounds__(HF_BLOCK, 4) void hf_trace_kernel(hf_dev_field f, s
                                   (__builtin_fabsf(ux * uy0 - uy * ux0) <= 0.05f * __builtin_fabsf(ux * uy0));
                 const bool coherent = __ballot(alive && !near) == 0ull;
                 // incoherent wave: the shared walk degenerates to handing the root to every live lane
-                walk_packet<MODE == 1>(f, s, tile, rs, alive, coherent, fx0, fy0, best);
+                walk_packet<MODE == 1>(f, s, rs, alive, coherent, fx0, fy0, best);
             }
             if (!valid) continue;
             if (MODE == 1) {

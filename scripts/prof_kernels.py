@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Run individual libhf kernels on the bench workload (for rocprofv3 / A-B timing).
 usage: python tools/prof_kernels.py [--grid 4096 --film 1024 --spp 64 --iters 5] kinds...
-kinds: fwd prelim si adj test miss mips"""
+kinds: fwd prelim si adj test miss mips sec_fwd sec_test (incoherent bounce / shadow rays from the primary hits)"""
 import argparse, ctypes as C, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -16,7 +16,7 @@ ap.add_argument("--grid", type=int, default=4096)
 ap.add_argument("--film", type=int, default=1024)
 ap.add_argument("--spp", type=int, default=64)
 ap.add_argument("--iters", type=int, default=5)
-ap.add_argument("kinds", nargs="*", default=["fwd", "prelim", "si", "adj", "test", "miss", "mips"])
+ap.add_argument("kinds", nargs="*", default=["fwd", "prelim", "si", "adj", "test", "miss", "mips", "sec_fwd", "sec_test"])
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 N, R = a.grid, a.film * a.film * a.spp
@@ -44,6 +44,17 @@ fn = {
 }
 fn["fwd"](); torch.cuda.synchronize()
 h = torch.isfinite(si[0]); gsi[0] = h.float(); gsi[1:4] = si[4:7] * h
+if any(k.startswith("sec") for k in a.kinds):
+    # secondary rays of SURVEY 8d: one cosine-hemisphere bounce + one shadow ray per primary hit
+    hit_idx = torch.nonzero(h).squeeze(1)
+    bounce, shadow = hf_amd.workload.secondary_rays(si[1:4][:, hit_idx], si[4:7][:, hit_idx], seed=0)
+    Rs = bounce.shape[1]
+    b_s = shape._rays_struct(bounce[0:3], bounce[3:6], bounce[6]); s_s = shape._rays_struct(shadow[0:3], shadow[3:6], shadow[6])
+    fn["sec_fwd"] = lambda: _capi.check(lib.hf_ray_intersect(shape._h, Rs, C.byref(b_s), flags, None, C.byref(pi_s), C.byref(si_s), st))
+    fn["sec_test"] = lambda: _capi.check(lib.hf_ray_test(shape._h, Rs, C.byref(s_s), None, hit8.data_ptr(), st))
+    nrays = {"sec_fwd": Rs, "sec_test": Rs}
+else:
+    nrays = {}
 for k in a.kinds:
     fn[k](); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -51,4 +62,5 @@ for k in a.kinds:
     for _ in range(a.iters): fn[k]()
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / a.iters
-    print(f"{k:7s} {ms:9.3f} ms  {R / ms / 1e3:10.1f} Mrays/s", flush=True)
+    nr = nrays.get(k, R)
+    print(f"{k:8s} {ms:9.3f} ms  {nr / ms / 1e3:10.1f} Mrays/s  ({nr} rays)", flush=True)
