@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Authored stand-in for BASELINE.json configs[4] ("inverse loop: 100 Adam steps recovering heights
+from multi-light renders"; the notebook in the reference snapshot contains no such loop -- SURVEY 0).
+
+A minimal direct-lighting differentiable render on top of the heightfield shape:
+    primary rays (orthographic)  ->  shape.ray_intersect (HIP traversal + fused SI)
+    image_k = albedo * max(0, <n, l_k>)  for K directional lights,  depth = t
+    loss = sum_k |image_k - target_k|^2 + lambda |depth - depth_target|^2     (valid pixels)
+    loss.backward()  ->  HIP adjoint scatters dL/dheight;  Adam step;  shape.parameters_changed()
+        (= mip rebuild, what scene.parameters_changed does once per optimiser step, scene.cpp:343-385)
+Geometry is attached (prb-style, no silhouette reparameterisation: SURVEY 8f rank 3 is not built).
+
+    python examples/inverse_heights.py [--grid 128 --film 256 --steps 100]
+With torch.distributed initialised (torchrun), every rank renders its own spp seed and the gradient
+texture is summed with one all-reduce per step.
+"""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import hf_amd  # noqa: E402
+
+LIGHTS = torch.tensor([[0.5, 0.2, 0.84], [-0.5, 0.3, 0.81], [0.1, -0.6, 0.79], [0.0, 0.0, 1.0]])
+
+
+def render(shape, ray, lights):
+    si = shape.ray_intersect(ray, hf_amd.RayFlags.All)
+    valid = si.is_valid()
+    shade = torch.clamp(torch.einsum("kc,cn->kn", lights, si.n), min=0.0) * valid       # [K, n]
+    depth = torch.where(valid, si.t, torch.zeros_like(si.t))
+    return shade, depth, valid
+
+
+def run(grid=128, film=256, spp=1, steps=100, lr=0.02, device="cuda", verbose=True, seed=0):
+    dev = torch.device(device)
+    lights = (LIGHTS / LIGHTS.norm(dim=1, keepdim=True)).to(dev)
+    target_h = hf_amd.workload.sine_heights(grid, grid, device=dev)
+    # camera looking down at 30 degrees off vertical so that every ray meets the surface
+    rays = hf_amd.workload.ortho_rays(film, film, spp, dev, seed=seed, origin=(0.6, 0.35, 2.0),
+                                      target=(0.0, 0.0, 0.25), scale=(0.95, 0.95, 1.0))
+    ray = hf_amd.Ray3f(rays[0:3], rays[3:6], rays[6])
+    target = hf_amd.Heightfield(heightfield=target_h, max_height=0.5)
+    with torch.no_grad():
+        tgt_shade, tgt_depth, tgt_valid = render(target, ray, lights)
+    shape = hf_amd.Heightfield(heightfield=torch.full_like(target_h, 0.5), max_height=0.5)
+    shape.heightfield.requires_grad_(True)
+    opt = torch.optim.Adam([shape.heightfield], lr=lr)                                    # optimizers.py:204-300
+    hist = []
+    t0 = time.perf_counter()
+    for it in range(steps):
+        opt.zero_grad(set_to_none=True)
+        shade, depth, valid = render(shape, ray, lights)
+        both = valid & tgt_valid
+        loss = (((shade - tgt_shade) ** 2).sum(0) * both).sum() / both.sum() \
+            + 10.0 * (((depth - tgt_depth) ** 2) * both).sum() / both.sum()
+        loss.backward()
+        hf_amd.allreduce_gradient(shape.heightfield.grad)
+        opt.step()
+        shape.parameters_changed(["heightfield"])                                         # rebuild the mips
+        hist.append(float(loss.detach()))
+        if verbose and (it % 10 == 0 or it == steps - 1):
+            err = float((shape.heightfield.detach() - target_h).abs().mean())
+            print(f"step {it:4d}  loss {hist[-1]:.6f}  mean |h - h*| {err:.5f}", flush=True)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    err = float((shape.heightfield.detach() - target_h).abs().mean())
+    if verbose:
+        print(f"{steps} Adam steps, {len(ray)} rays/step: {wall:.2f} s wall-clock ({1e3 * wall / steps:.1f} ms/step)")
+    return hist, err, wall
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--grid", type=int, default=128)
+    ap.add_argument("--film", type=int, default=256)
+    ap.add_argument("--spp", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--lr", type=float, default=0.02)
+    a = ap.parse_args()
+    run(a.grid, a.film, a.spp, a.steps, a.lr)

@@ -290,7 +290,8 @@ __device__ __forceinline__ bool walk_subtree(const hf_dev_field &f, const Src &s
 ) {
     auto loadh = [&src](int i, int j) { return src.height(i, j); };
     bool hit_any = false, fin = false, pblk = false;
-    uint32_t X = X0, Y = Y0, cur = 0, stk = 0, pend = 0;
+    uint32_t X = X0, Y = Y0, cur = 0, pend = 0;
+    uint64_t stk = 0; // 4 bits per level below L0; L0 can be the root of a 2^15-cell grid (incoherent waves)
     int L = L0, pc0 = 0, pr0 = 0;
     float pfx = 0.f, pfy = 0.f; // order-space origin of the parked block
     if (L0 == 1) { // the root is itself a level-1 node: one block, no walk
@@ -309,7 +310,7 @@ __device__ __forceinline__ bool walk_subtree(const hf_dev_field &f, const Src &s
         while (!fin && !pblk) {
             WCOUNT(3);
             while (cur == 0u && L < L0) { // node exhausted: pop
-                cur = stk & 15u; stk >>= 4;
+                cur = (uint32_t) stk & 15u; stk >>= 4;
                 X >>= 1; Y >>= 1; ++L;
             }
             if (cur == 0u) { fin = true; break; }
@@ -327,7 +328,7 @@ __device__ __forceinline__ bool walk_subtree(const hf_dev_field &f, const Src &s
                 continue;
             }
             WCOUNT(5);
-            stk = (stk << 4) | cur;
+            stk = (stk << 4) | (uint64_t) cur;
             X = cx; Y = cy; --L;
             hf_quad q;
             src.children(L, X ^ (fxm >> L), Y ^ (fym >> L), q);

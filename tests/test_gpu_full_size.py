@@ -1,0 +1,139 @@
+"""Parity at BASELINE.json's full sizes (configs[1..3]) through the C ABI.
+
+configs[1] 1024^2 grid, 512^2 sensor @16spp : every ray against the oracle (bit-exact prim_index / t)
+configs[2] 2048^2 grid, adjoint dL/dheight   : L = sum t, against float64 central finite differences
+                                               (test_ad_integrators.py:1001-1012 methodology), whole
+                                               texture in L2 and a 32x32 texel sub-block texel by texel
+configs[3] 4096^2 grid, 1024^2 @64spp        : size-independent properties on all 67.1 M rays (fused ==
+                                               unfused, ray_test == is_valid, run-to-run identical,
+                                               linearity of the adjoint) + the oracle on a 1 M-ray sample
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(hf, N, film, spp, count=None, start=0):
+    dev = torch.device("cuda", 0)
+    h = hf.workload.sine_heights(N, N, device=dev)
+    shape = hf.Heightfield(heightfield=h, max_height=0.5)
+    rays = hf.workload.ortho_rays(film, film, spp, dev, start=start, count=count)
+    ray = hf.Ray3f(rays[0:3], rays[3:6], rays[6])
+    return shape, h, rays, ray
+
+
+def test_config1_all_rays_vs_oracle(hf, oracle):
+    shape, h, rays, ray = _setup(hf, 1024, 512, 16)
+    pi = shape.ray_intersect_preliminary(ray)
+    f = oracle.OracleField(h.cpu().numpy(), max_height=0.5)
+    t, u, v, prim = f.ray_intersect_preliminary(rays.cpu().numpy(), nthreads=16)
+    assert np.array_equal(prim, pi.prim_index.cpu().numpy().view(np.uint32))
+    assert np.array_equal(t, pi.t.cpu().numpy())            # bit-exact, inf included
+    assert np.array_equal(u, pi.prim_uv[0].cpu().numpy()) and np.array_equal(v, pi.prim_uv[1].cpu().numpy())
+    assert 0.2 < np.isfinite(t).mean() < 0.3
+    assert torch.equal(shape.ray_test(ray), pi.is_valid())
+    si_o = f.compute_surface_interaction(rays.cpu().numpy(), t, u, v, prim, nthreads=16)
+    si = shape.ray_intersect(ray)
+    for k, val in (("p", si.p), ("n", si.n), ("uv", si.uv), ("dp_du", si.dp_du), ("dp_dv", si.dp_dv)):
+        assert np.allclose(val.cpu().numpy(), si_o[k], rtol=1e-5, atol=2e-6), k
+
+
+def _mt_t(o, d, p0, p1, p2):
+    """float64 Moeller-Trumbore t for arrays of rays / triangles ([n,3])"""
+    e1, e2 = p1 - p0, p2 - p0
+    pvec = np.cross(d, e2)
+    inv = 1.0 / np.einsum("ij,ij->i", e1, pvec)
+    qvec = np.cross(o - p0, e1)
+    return np.einsum("ij,ij->i", e2, qvec) * inv
+
+
+def test_config2_adjoint_vs_oracle_and_float64_finite_differences(hf, oracle):
+    """L = sum over hits of w * t.  (1) parity bar: the HIP gradient equals the fp32 oracle's within 1e-5
+    (L2).  (2) truth check: float64 central differences of the same loss.  fp32 Moeller-Trumbore resolves
+    the barycentrics of a hit on a 1e-3-wide cell, seen from 3 units away, to only ~3e-4, and t itself
+    to ~2e-5 for grazing hits, so the fp32 gradient (the reference's llvm_ad_rgb is fp32 too) can agree
+    with float64 only to that level: rays with |n.d| <= 0.1 get w = 0 and the tolerance is 2e-3."""
+    N, s = 2048, 0.5
+    shape, h, rays, ray = _setup(hf, N, 512, 16)
+    si = shape.ray_intersect(ray)
+    pi = hf.PreliminaryIntersection3f(si.t, si.prim_uv, si.prim_index, shape)
+    hit = pi.is_valid()
+    w = hit & ((si.n * ray.d).sum(0).abs() > 0.1)
+    g = torch.zeros((18, len(ray)), device=h.device)
+    g[0] = w.float()
+    grad32 = shape.adjoint(ray, pi, g)
+    grad = grad32.double().cpu().numpy()
+    # (1) fp32 oracle on the same rays
+    f = oracle.OracleField(h.cpu().numpy(), max_height=s)
+    rn = rays.cpu().numpy()
+    go = f.adjoint(rn, pi.t.cpu().numpy(), pi.prim_uv[0].cpu().numpy(), pi.prim_uv[1].cpu().numpy(),
+                   pi.prim_index.cpu().numpy().view(np.uint32), {"t": w.float().cpu().numpy()[None]}, nthreads=16)
+    assert np.linalg.norm(go - grad) <= 1e-5 * np.linalg.norm(go)
+    # (2) float64 central differences of t w.r.t. the three vertex heights of each ray's triangle
+    r = rays[:, w].double().cpu().numpy()
+    prim = pi.prim_index[w].cpu().numpy().astype(np.int64)
+    cell, tri = prim >> 1, prim & 1
+    cx, cy = cell % (N - 1), cell // (N - 1)
+    vi = np.where(tri[:, None] == 0, np.stack([cy, cy, cy + 1], 1), np.stack([cy + 1, cy + 1, cy], 1))
+    vj = np.where(tri[:, None] == 0, np.stack([cx, cx + 1, cx], 1), np.stack([cx + 1, cx, cx + 1], 1))
+    H = h.double().cpu().numpy()
+    def verts(dh, k):
+        P = []
+        for c in range(3):
+            z = H[vi[:, c], vj[:, c]] + (dh if c == k else 0.0)
+            P.append(np.stack([vj[:, c] * 2.0 / (N - 1) - 1.0, vi[:, c] * 2.0 / (N - 1) - 1.0, z * s], 1))
+        return P
+    o, d = r[0:3].T, r[3:6].T
+    eps = 1e-6   # heights are O(1), a cell is 1e-3 wide: keep the step far inside the linear range (float64)
+    fd = np.zeros((N, N))
+    for k in range(3):
+        tp = _mt_t(o, d, *verts(+eps, k)); tm = _mt_t(o, d, *verts(-eps, k))
+        np.add.at(fd, (vi[:, k], vj[:, k]), (tp - tm) / (2 * eps))
+    assert np.abs(fd).max() > 1.0
+    assert np.linalg.norm(grad - fd) <= 2e-3 * np.linalg.norm(fd)
+    # 32x32 texel sub-block around the largest gradient, texel by texel
+    iy, ix = np.unravel_index(np.argmax(np.abs(fd)), fd.shape)
+    y0, x0 = min(max(iy - 16, 0), N - 32), min(max(ix - 16, 0), N - 32)
+    blk_g, blk_f = grad[y0:y0 + 32, x0:x0 + 32], fd[y0:y0 + 32, x0:x0 + 32]
+    assert np.count_nonzero(blk_f) > 100
+    assert np.abs(blk_g - blk_f).max() <= 1e-2 * np.abs(blk_f).max()
+
+
+def test_config3_properties_at_full_size(hf, oracle):
+    N, film, spp = 4096, 1024, 64
+    shape, h, rays, ray = _setup(hf, N, film, spp)
+    R = len(ray)
+    assert R == 67108864
+    pi = shape.ray_intersect_preliminary(ray)
+    pi2 = shape.ray_intersect_preliminary(ray)                # run-to-run identical (no atomics in the forward)
+    assert torch.equal(pi.t, pi2.t) and torch.equal(pi.prim_index, pi2.prim_index)
+    del pi2
+    valid = pi.is_valid()
+    assert torch.equal(shape.ray_test(ray), valid)
+    # fused == unfused on a strided subset (full records would not add information)
+    sub = torch.arange(0, R, 16, device=rays.device)
+    rs = rays[:, sub].contiguous()
+    ray_s = hf.Ray3f(rs[0:3], rs[3:6], rs[6])
+    fused = shape.ray_intersect(ray_s)
+    pis = shape.ray_intersect_preliminary(ray_s)
+    assert torch.equal(pis.t, pi.t[sub]) and torch.equal(pis.prim_index, pi.prim_index[sub])   # independent of batch composition
+    si = pis.compute_surface_interaction(ray_s)
+    for a, b in ((fused.t, si.t), (fused.p, si.p), (fused.n, si.n), (fused.uv, si.uv), (fused.dp_du, si.dp_du)):
+        assert torch.equal(a, b)
+    # linearity of the adjoint: A(g1) + A(g2) == A(g1 + g2) up to float-atomic summation order
+    gen = torch.Generator(device=rays.device); gen.manual_seed(12345)
+    g1 = torch.randn((18, sub.numel()), device=rays.device, generator=gen)
+    g2 = torch.randn((18, sub.numel()), device=rays.device, generator=gen)
+    a1 = shape.adjoint(ray_s, pis, g1).double(); a2 = shape.adjoint(ray_s, pis, g2).double()
+    a12 = shape.adjoint(ray_s, pis, g1 + g2).double()
+    assert torch.linalg.norm(a1 + a2 - a12) <= 1e-5 * torch.linalg.norm(a12)
+    # the oracle on a 1 M-ray random sample of the full wavefront
+    rng = np.random.default_rng(7)
+    samp = np.sort(rng.choice(R, 1 << 20, replace=False))
+    samp_t = torch.from_numpy(samp).to(rays.device)
+    f = oracle.OracleField(h.cpu().numpy(), max_height=0.5)
+    t, u, v, prim = f.ray_intersect_preliminary(rays[:, samp_t].cpu().numpy(), nthreads=16)
+    assert np.array_equal(prim, pi.prim_index[samp_t].cpu().numpy().view(np.uint32))
+    assert np.array_equal(t, pi.t[samp_t].cpu().numpy())
