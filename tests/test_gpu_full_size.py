@@ -137,3 +137,25 @@ def test_config3_properties_at_full_size(hf, oracle):
     t, u, v, prim = f.ray_intersect_preliminary(rays[:, samp_t].cpu().numpy(), nthreads=16)
     assert np.array_equal(prim, pi.prim_index[samp_t].cpu().numpy().view(np.uint32))
     assert np.array_equal(t, pi.t[samp_t].cpu().numpy())
+
+
+def test_large_non_square_grid_incoherent_rays(hf, oracle):
+    """1500 x 700 grid (not a power of two, top = 11, padded quadtree), general affine to_world, 300 k
+    incoherent rays incl. origins inside the bound and finite maxt: every ray against the oracle."""
+    import common
+    rng = np.random.default_rng(21)
+    W, H = 1500, 700
+    u = np.arange(W) / (W - 1.0); v = np.arange(H)[:, None] / (H - 1.0)
+    h = (0.5 + 0.3 * np.sin(2 * np.pi * 9 * u) * np.cos(2 * np.pi * 5 * v) + 0.1 * rng.uniform(-1, 1, (H, W))).astype(np.float32)
+    tw = common.affine(9)
+    f = oracle.OracleField(h, max_height=0.35, to_world=tw)
+    shape = hf.Heightfield(heightfield=torch.from_numpy(h), max_height=0.35, to_world=torch.from_numpy(tw))
+    r = common.to_world_rays(np.concatenate([common.random_rays(200000, rng, 0.35), common.inside_rays(100000, rng, 0.35)], 1), tw)
+    rt = torch.from_numpy(r).cuda()
+    ray = hf.Ray3f(rt[0:3].contiguous(), rt[3:6].contiguous(), rt[6].contiguous())
+    pi = shape.ray_intersect_preliminary(ray)
+    t, uu, vv, prim = f.ray_intersect_preliminary(r, nthreads=16)
+    assert np.array_equal(prim, pi.prim_index.cpu().numpy().view(np.uint32))
+    assert np.array_equal(t, pi.t.cpu().numpy())
+    assert np.array_equal(f.ray_test(r, nthreads=16), shape.ray_test(ray).cpu().numpy())
+    assert 0.3 < np.isfinite(t).mean() < 0.99
