@@ -477,11 +477,11 @@ struct hf_si_dev {
     float *t, *p[3], *n[3], *uv[2], *sh_n[3], *dp_du[3], *dp_dv[3], *bt, *sh_s[3], *sh_t[3], *wi[3];
 };
 
-__device__ __forceinline__ void st(float *p, size_t i, float v) { if (p) p[i] = v; }
+// record stores are write-once streams (72 B/ray): non-temporal, so that they do not push the mip
+// and height lines of concurrently traversing waves out of L2
+__device__ __forceinline__ void st(float *p, size_t i, float v) { if (p) __builtin_nontemporal_store(v, &p[i]); }
 __device__ __forceinline__ void st3(float *const p[3], size_t i, v3 v) {
-    if (p[0]) p[0][i] = v.x;
-    if (p[1]) p[1][i] = v.y;
-    if (p[2]) p[2][i] = v.z;
+    st(p[0], i, v.x); st(p[1], i, v.y); st(p[2], i, v.z);
 }
 
 __device__ __forceinline__ void store_si(const hf_si_dev &out, size_t i, const hf_si_rec &si, uint32_t flags) {
@@ -521,12 +521,18 @@ __global__ __launch_bounds__(HF_BLOCK, 4) void hf_trace_kernel(hf_dev_field f, s
     __shared__ hf_lds_mips s;
     stage_mips(f, s);
     const unsigned lane = threadIdx.x & 63u;
+    // The counter hands out grab numbers; even grabs walk the wavefront from its front, odd ones from
+    // its back.  Rays that miss the bound only stream (memory/atomic-bound), rays that traverse are
+    // issue-bound: in rendered wavefronts the two come in large contiguous regions, and two fronts
+    // let them overlap in time instead of running one after the other.
+    const unsigned long long n_grabs = (n + HF_GRAB - 1) / HF_GRAB;
     for (;;) {
-        unsigned long long base = 0;
-        if (lane == 0) base = atomicAdd(counter, (unsigned long long) HF_GRAB);
-        base = ((unsigned long long) (uint32_t) __builtin_amdgcn_readfirstlane((int) (base >> 32)) << 32) |
-               (unsigned long long) (uint32_t) __builtin_amdgcn_readfirstlane((int) (base & 0xffffffffull));
-        if (base >= n) break;
+        unsigned long long g = 0;
+        if (lane == 0) g = atomicAdd(counter, 1ull);
+        g = ((unsigned long long) (uint32_t) __builtin_amdgcn_readfirstlane((int) (g >> 32)) << 32) |
+            (unsigned long long) (uint32_t) __builtin_amdgcn_readfirstlane((int) (g & 0xffffffffull));
+        if (g >= n_grabs) break;
+        const unsigned long long base = ((g & 1ull) ? (n_grabs >> 1) - 1ull - (g >> 1) : (n_grabs >> 1) + (g >> 1)) * HF_GRAB;
 #pragma unroll 1
         for (unsigned sub = 0; sub < HF_GRAB; sub += 64) {
             // all 64 lanes stay in the loop body (the shared walk relies on whole-wave ballots);
