@@ -583,9 +583,10 @@ __global__ __launch_bounds__(HF_BLOCK, 4) void hf_trace_kernel(hf_dev_field f, s
     }
 }
 
+#define HF_FLAT_GRID_CAP (256 * 64)
 static int grid_for(size_t n) {
     size_t blocks = (n + HF_BLOCK - 1) / HF_BLOCK;
-    const size_t cap = 256 * 8; // 256 CUs x 8 resident blocks of 256 threads
+    const size_t cap = HF_FLAT_GRID_CAP; // grid-stride kernels: many short blocks balance better than one resident set
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     return (int) blocks;
@@ -667,13 +668,24 @@ void hf_launch_si(const hf_dev_field &f, size_t n, const hf_rays_t *rays, const 
 // ---------------------------------------------------------------------------------
 #define HF_ADJ_TILE 32 // texels per side of the per-wave LDS accumulation tile
 
+// bitwise OR over the 64 lanes of a wave (DPP within rows of 16, readlane across the four rows)
+__device__ __forceinline__ uint32_t wave_or(uint32_t v) {
+    int x = (int) v;
+    x |= __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
+    x |= __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, true);  // quad_perm [2,3,0,1]
+    x |= __builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, true); // row_half_mirror
+    x |= __builtin_amdgcn_update_dpp(0, x, 0x140, 0xF, 0xF, true); // row_mirror
+    return (uint32_t) (__builtin_amdgcn_readlane(x, 0) | __builtin_amdgcn_readlane(x, 16) |
+                       __builtin_amdgcn_readlane(x, 32) | __builtin_amdgcn_readlane(x, 48));
+}
+
 struct hf_grad_dev {
     const float *t, *p[3], *n[3], *uv[2], *sh_n[3], *dp_du[3], *dp_dv[3];
 };
 __device__ __forceinline__ float ld(const float *p, size_t i) { return p ? p[i] : 0.f; }
 __device__ __forceinline__ v3 ld3(const float *const p[3], size_t i) { return mk3(ld(p[0], i), ld(p[1], i), ld(p[2], i)); }
 
-__global__ __launch_bounds__(HF_BLOCK) void hf_adjoint_kernel(hf_dev_field f, size_t n, hf_rays_dev rays,
+__global__ __launch_bounds__(HF_BLOCK, 5) void hf_adjoint_kernel(hf_dev_field f, size_t n, hf_rays_dev rays,
                                                               hf_pi_cdev pi, const uint8_t *__restrict__ active,
                                                               hf_grad_dev g, uint32_t flags,
                                                               float *__restrict__ grad_h, float *go0, float *go1,
@@ -804,20 +816,27 @@ __global__ __launch_bounds__(HF_BLOCK) void hf_adjoint_kernel(hf_dev_field f, si
             // tile anchor from the first scattering lane (wave-uniform)
             const int src = __builtin_ctzll(sm);
             const int ar = __shfl(vr[0], src) - HF_ADJ_TILE / 4, ac = __shfl(vc[0], src) - HF_ADJ_TILE / 4;
+            uint32_t rows = 0u; // tile rows this lane added to
             if (scatter) {
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
                     const int rr = vr[k] - ar, cc = vc[k] - ac;
-                    if ((unsigned) rr < (unsigned) HF_ADJ_TILE && (unsigned) cc < (unsigned) HF_ADJ_TILE)
+                    if ((unsigned) rr < (unsigned) HF_ADJ_TILE && (unsigned) cc < (unsigned) HF_ADJ_TILE) {
                         atomicAdd(acc + rr * HF_ADJ_TILE + cc, gh[k]);
-                    else
+                        rows |= 1u << rr;
+                    } else {
                         atomicAdd(grad_h + (size_t) vr[k] * f.W + vc[k], gh[k]);
+                    }
                 }
             }
-            // flush: 64 consecutive tile entries (two 32-texel row segments) per wave-instruction
-            for (int k = lane; k < HF_ADJ_TILE * HF_ADJ_TILE; k += 64) {
+            rows = wave_or(rows);
+            // flush the touched rows: 64 consecutive tile entries (two 32-texel row segments) per wave-instruction
+#pragma unroll 1
+            while (rows != 0u) { // wave-uniform
+                const int k2 = __builtin_ctz(rows) >> 1;
+                rows &= ~(3u << (2 * k2));
+                const int k = k2 * 64 + lane;
                 const float v = acc[k];
-                if (__ballot(v != 0.f) == 0ull) continue;
                 if (v != 0.f) {
                     const int rr = ar + k / HF_ADJ_TILE, cc = ac + k % HF_ADJ_TILE;
                     atomicAdd(grad_h + (size_t) rr * f.W + cc, v);
