@@ -13,6 +13,7 @@ struct hf_field {
     hf_dev_field dev;   // device view handed to kernels by value
     float *d_heights;   // owned copy of the heights
     float2 *d_mip;      // owned min/max pyramid
+    float4 *d_shear;    // owned sheared bounds of the fine levels
     size_t mip_nodes;
     int device;
     hipEvent_t built;   // completion of the last hf_set_heights*
@@ -121,20 +122,23 @@ extern "C" int hf_create(const hf_desc_t *desc, hf_field_t **out) {
     hf->mip_nodes = off;
     hipError_t e = hipMalloc((void **) &hf->d_heights, sizeof(float) * (size_t) d.W * d.H);
     if (e == hipSuccess) e = hipMalloc((void **) &hf->d_mip, sizeof(float2) * off);
+    if (e == hipSuccess) e = hipMalloc((void **) &hf->d_shear, sizeof(float4) * 3 * (hf_shear_records(top) + 1));
     if (e == hipSuccess) e = hipMalloc((void **) &hf->d_counters, sizeof(unsigned long long) * 16 * HF_NUM_COUNTERS);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&hf->built, hipEventDisableTiming);
     if (e != hipSuccess) {
         if (hf->d_heights) (void) hipFree(hf->d_heights);
         if (hf->d_mip) (void) hipFree(hf->d_mip);
+        if (hf->d_shear) (void) hipFree(hf->d_shear);
         if (hf->d_counters) (void) hipFree(hf->d_counters);
         free(hf);
         return fail(e == hipErrorOutOfMemory ? HF_ENOMEM : HF_EDEVICE, "hf_create: %s", hipGetErrorString(e));
     }
     d.h = hf->d_heights;
     d.mip = hf->d_mip;
+    d.shear = hf->d_shear;
     // heights start as zero; build the pyramid so the handle is always traceable
     HF_HIP(hipMemsetAsync(hf->d_heights, 0, sizeof(float) * (size_t) d.W * d.H, nullptr));
-    hf_launch_build_mips(d, hf->d_mip, nullptr);
+    hf_launch_build_mips(d, hf->d_mip, hf->d_shear, nullptr);
     HF_HIP(hipEventRecord(hf->built, nullptr));
     HF_HIP(hipStreamSynchronize(nullptr));
     *out = hf;
@@ -148,6 +152,7 @@ extern "C" int hf_destroy(hf_field_t *hf) {
     (void) hipEventDestroy(hf->built);
     (void) hipFree(hf->d_heights);
     (void) hipFree(hf->d_mip);
+    (void) hipFree(hf->d_shear);
     (void) hipFree(hf->d_counters);
     free(hf);
     return HF_OK;
@@ -159,7 +164,7 @@ extern "C" int hf_set_heights(hf_field_t *hf, const float *d_heights, hf_stream_
     const size_t bytes = sizeof(float) * (size_t) hf->dev.W * hf->dev.H;
     if (d_heights != hf->d_heights)
         HF_HIP(hipMemcpyAsync(hf->d_heights, d_heights, bytes, hipMemcpyDeviceToDevice, st));
-    hf_launch_build_mips(hf->dev, hf->d_mip, st);
+    hf_launch_build_mips(hf->dev, hf->d_mip, hf->d_shear, st);
     HF_HIP(hipGetLastError());
     HF_HIP(hipEventRecord(hf->built, st));
     return HF_OK;

@@ -74,6 +74,7 @@ __device__ __forceinline__ v3 xform_vec(const float *m, v3 v) {
 struct hf_dev_field {
     const float *h;    // W*H heights, row-major
     const float2 *mip; // (4^top - 1)/3 nodes
+    const float4 *shear; // sheared bounds of the fine levels, 3 float4 per node (see hf_shear_rec)
     int32_t W, H;
     int32_t top;  // max(ceil(log2(max(W-1,H-1))), 1); mip[1] is the global (min,max)
     float s, sx, sy, iu, iv;
@@ -86,6 +87,20 @@ __host__ __device__ __forceinline__ int hf_level_w(int cells, int l) { return (c
 // offset of pyramid depth k: (4^k - 1)/3 + 1 (entry 0 is padding so that every depth >= 1 starts
 // on an even index: the two children of a node that share a row are one aligned 16-byte load)
 __host__ __device__ __forceinline__ uint32_t hf_depth_off(int k) { return (0x55555555u & ((1u << (2 * k)) - 1u)) + 1u; }
+
+// Sheared bounds.  Min/max boxes are loose on steep terrain: a node on a slope spans a large
+// z range although the surface stays close to a plane.  Nodes of levels 2..HF_SHEAR_TOP therefore
+// also carry a plane  z = c + a (x - xc) + b (y - yc)  through their corner heights (x, y in cell
+// units, (xc,yc) the node centre) and, per child, the exact range of  z - plane  over the child's
+// vertices: the box test of the walk then runs in the sheared coordinate  w = z - plane, in which
+// the ray is still a straight line.  Any plane is valid (the ranges are exact for the plane that is
+// stored); record = { (a, b, c, |a|+|b|), (lo0, hi0, lo1, hi1), (lo2, hi2, lo3, hi3) }, children in
+// actual order j = 2 jy + jx, absent children (+inf, -inf).  Same coarse-first indexing as the
+// pyramid: node (ix,iy) of level L = depth k = top - L is record  hf_depth_off(k) - 1 + (iy << k) + ix.
+#define HF_SHEAR_TOP 5
+__host__ __device__ __forceinline__ size_t hf_shear_records(int top) { // depths 0 .. top-2 (levels 2 .. top)
+    return top >= 2 ? (size_t) hf_depth_off(top - 1) - 1u : 0u;
+}
 
 struct hf_hit {
     float t, u, v;

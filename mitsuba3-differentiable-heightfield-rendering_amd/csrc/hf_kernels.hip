@@ -63,8 +63,49 @@ __global__ __launch_bounds__(HF_BLOCK) void hf_mip_reduce_kernel(const float2 *_
     out[idx] = make_float2(fminf(fminf(a.x, b.x), fminf(d.x, e.x)), fmaxf(fmaxf(a.y, b.y), fmaxf(d.y, e.y)));
 }
 
-void hf_launch_build_mips(const hf_dev_field &f, float2 *mip, hipStream_t stream) {
+// sheared bounds of level L (see hf_device.h): one thread per (node, child)
+__global__ __launch_bounds__(HF_BLOCK) void hf_shear_kernel(const float *__restrict__ h, int W, int H, float s, int L,
+                                                           int sh, float4 *__restrict__ out) {
+    const int idx = blockIdx.x * HF_BLOCK + threadIdx.x;
+    if (idx >= (4 << (2 * sh))) return;
+    const int j = idx & 3, node = idx >> 2, iy = node >> sh, ix = node & ((1 << sh) - 1);
+    const int size = 1 << L, S = size >> 1, x0 = ix * size, y0 = iy * size;
+    // plane through the (clamped) corner heights; any plane is valid, the ranges below are exact for it
+    const int xa = min(x0, W - 1), xb = min(x0 + size, W - 1), ya = min(y0, H - 1), yb = min(y0 + size, H - 1);
+    const float z00 = h[(size_t) ya * W + xa] * s, z10 = h[(size_t) ya * W + xb] * s;
+    const float z01 = h[(size_t) yb * W + xa] * s, z11 = h[(size_t) yb * W + xb] * s;
+    const float inv = 0.5f / (float) size;
+    const float a = ((z10 - z00) + (z11 - z01)) * inv, b = ((z01 - z00) + (z11 - z10)) * inv;
+    const float c = 0.25f * ((z00 + z10) + (z01 + z11));
+    const float xc = (float) (x0 + S), yc = (float) (y0 + S);
+    // child j: cells [cj0, cj1] x [ci0, ci1] that exist, then their vertices
+    const int cj0 = x0 + (j & 1) * S, cj1 = min(cj0 + S - 1, W - 2);
+    const int ci0 = y0 + (j >> 1) * S, ci1 = min(ci0 + S - 1, H - 2);
+    float lo = __builtin_inff(), hi = -__builtin_inff();
+    if (ci0 <= ci1 && cj0 <= cj1) {
+        for (int i = ci0; i <= ci1 + 1; ++i) {
+            const float row = __builtin_fmaf(b, (float) i - yc, c);
+            for (int jj = cj0; jj <= cj1 + 1; ++jj) {
+                const float w = h[(size_t) i * W + jj] * s - __builtin_fmaf(a, (float) jj - xc, row);
+                lo = fminf(lo, w); hi = fmaxf(hi, w);
+            }
+        }
+        // rounding of the plane evaluation above
+        const float eps = 1e-6f * (__builtin_fabsf(c) + (__builtin_fabsf(a) + __builtin_fabsf(b)) * (float) size);
+        lo -= eps; hi += eps;
+    }
+    float *rec = (float *) (out + (size_t) node * 3);
+    if (j == 0) { rec[0] = a; rec[1] = b; rec[2] = c; rec[3] = __builtin_fabsf(a) + __builtin_fabsf(b); }
+    rec[4 + 2 * j] = lo; rec[5 + 2 * j] = hi;
+}
+
+void hf_launch_build_mips(const hf_dev_field &f, float2 *mip, float4 *shear, hipStream_t stream) {
     const int top = f.top;
+    for (int L = 2; L <= top && L <= HF_SHEAR_TOP; ++L) {
+        const int k = top - L, n = 4 << (2 * k), grid = (n + HF_BLOCK - 1) / HF_BLOCK;
+        hipLaunchKernelGGL(hf_shear_kernel, dim3(grid), dim3(HF_BLOCK), 0, stream, f.h, f.W, f.H, f.s, L, k,
+                           shear + (size_t) (hf_depth_off(k) - 1u) * 3);
+    }
     (void) hipMemsetAsync(mip, 0, sizeof(float2), stream); // padding entry
     for (int k = top - 1; k >= 0; --k) {
         const int n = 1 << (2 * k), grid = (n + HF_BLOCK - 1) / HF_BLOCK;
@@ -116,11 +157,12 @@ struct hf_quad {
 
 // Overlap mask (ACTUAL numbering j = 2*jy + jx) of the fat ray segment [0,thi] with the four
 // boxes of the 2x2 block whose order-space origin is (fX,fY), box size S; tent[j] = entry
-// parameter of box j.  Direction is >= 0 in order space, so a box's entry planes are its low
+// parameter of box j.  The third coordinate of the ray is the line  gz + t dz  (+/- mz): the height
+// for min/max boxes, the sheared height for sheared bounds.  Direction is >= 0 in order space, so a box's entry planes are its low
 // faces and its exit planes its high faces; v_max3/v_min3 drop the NaN of 0*inf (origin of an
 // axis-parallel ray exactly on a face plane).
 __device__ __forceinline__ uint32_t child_mask(const hf_trav &r, float fX, float fY, float S, const hf_quad &q,
-                                               float thi, float tent[4]) {
+                                               float gz, float dz, float mz, float thi, float tent[4]) {
     const float ex = fX - r.gxm, lx = fX + S - r.gxp; // entry / exit plane offsets of order column 0
     const float ey = fY - r.gym, ly = fY + S - r.gyp;
     const float x0lo = __builtin_fmaf(S, r.nx0, ex) * r.idx, x0hi = __builtin_fmaf(S, r.nx0, lx) * r.idx;
@@ -133,8 +175,8 @@ __device__ __forceinline__ uint32_t child_mask(const hf_trav &r, float fX, float
         const float xlo = (j & 1) ? x1lo : x0lo, xhi = (j & 1) ? x1hi : x0hi;
         const float ylo = (j & 2) ? y1lo : y0lo, yhi = (j & 2) ? y1hi : y0hi;
         const float t0 = fmaxf(fmaxf(xlo, ylo), 0.f), t1 = fminf(fminf(xhi, yhi), thi);
-        const float za = __builtin_fmaf(t0, r.dz, r.gz), zb = __builtin_fmaf(t1, r.dz, r.gz);
-        const bool ok = (t0 <= t1) & (fminf(za, zb) - r.mz <= q.hi[j]) & (fmaxf(za, zb) + r.mz >= q.lo[j]);
+        const float za = __builtin_fmaf(t0, dz, gz), zb = __builtin_fmaf(t1, dz, gz);
+        const bool ok = (t0 <= t1) & (fminf(za, zb) - mz <= q.hi[j]) & (fmaxf(za, zb) + mz >= q.lo[j]);
         tent[j] = t0;
         m |= ok ? (1u << j) : 0u;
     }
@@ -222,12 +264,32 @@ __device__ __forceinline__ bool setup_ray(const hf_dev_field &f, float2 zr, v3 o
     return true;
 }
 
-// 3x3 heights -> the 2x2 cells of a block as exact boxes -> mask (ACTUAL numbering j = 2*jy+jx)
+// The ray in the sheared coordinate  w = z - (c + a (x - xc) + b (y - yc))  of a node whose centre is
+// (xc,yc) in order space: w(t) = gz + t dz.  (a,b) are stored for actual coordinates; mirroring an
+// axis into order space flips the sign of its slope.  mz grows by the slope times the xy uncertainty
+// of the walk (the margin m) plus the rounding of the line itself, whose terms are as large as
+// slope x grid size.
+__device__ __forceinline__ void shear_line(const hf_dev_field &f, const hf_ray_state &rs, bool fx, bool fy, float a,
+                                           float b, float c, float sab, float xc, float yc, float &gz, float &dz,
+                                           float &mz) {
+    const hf_trav &r = rs.r;
+    const float ao = fx ? -a : a, bo = fy ? -b : b;
+    const float ux = 0.5f * (r.gxm + r.gxp) - xc, uy = 0.5f * (r.gym + r.gyp) - yc;
+    gz = __builtin_fmaf(-bo, uy, __builtin_fmaf(-ao, ux, r.gz - c));
+    const float dxo = __builtin_fabsf(rs.od.x) * (0.5f * (float) (f.W - 1));
+    const float dyo = __builtin_fabsf(rs.od.y) * (0.5f * (float) (f.H - 1));
+    dz = __builtin_fmaf(-bo, dyo, __builtin_fmaf(-ao, dxo, r.dz));
+    const float m = 0.5f * (r.gxm - r.gxp) + 2e-6f * (float) (1 << f.top);
+    mz = __builtin_fmaf(sab, m, r.mz);
+}
+
+// 3x3 heights -> the 2x2 cells of a block as exact (sheared) boxes -> mask (ACTUAL numbering j = 2*jy+jx)
 // of the cells the fat ray can hit.  (c0,r0) = actual lower-left cell of the block, (fX,fY) = its
 // order-space origin.  The triangles themselves are tested later, wave-converged (walk_subtree).
 template <typename LoadH>
-__device__ __forceinline__ uint32_t block_cells(const hf_dev_field &f, const hf_trav &r, int c0, int r0, float fX,
-                                                float fY, float thi, LoadH loadh) {
+__device__ __forceinline__ uint32_t block_cells(const hf_dev_field &f, const hf_ray_state &rs, bool fx, bool fy, int c0,
+                                                int r0, float fX, float fY, float thi, LoadH loadh) {
+    const hf_trav &r = rs.r;
     const int cw = f.W - 1, ch = f.H - 1;
     const int ca = min(max(c0, 0), f.W - 1), cb = min(max(c0 + 1, 0), f.W - 1), cc = min(max(c0 + 2, 0), f.W - 1);
     const int ra = min(max(r0, 0), f.H - 1), rb = min(max(r0 + 1, 0), f.H - 1), rc = min(max(r0 + 2, 0), f.H - 1);
@@ -236,18 +298,28 @@ __device__ __forceinline__ uint32_t block_cells(const hf_dev_field &f, const hf_
     const float z20 = loadh(rc, ca) * f.s, z21 = loadh(rc, cb) * f.s, z22 = loadh(rc, cc) * f.s;
     const bool vx0 = (c0 >= 0) & (c0 < cw), vx1 = (c0 + 1 >= 0) & (c0 + 1 < cw);
     const bool vy0 = (r0 >= 0) & (r0 < ch), vy1 = (r0 + 1 >= 0) & (r0 + 1 < ch);
+    // sheared by the plane through the block's corner heights (hf_device.h): w = z - plane at the 9 vertices
+    const float a = 0.25f * ((z02 - z00) + (z22 - z20)), b = 0.25f * ((z20 - z00) + (z22 - z02));
+    const float c = 0.25f * ((z00 + z02) + (z20 + z22));
+    const float p0 = c - b, p2 = c + b;
+    const float w00 = z00 - (p0 - a), w01 = z01 - p0, w02 = z02 - (p0 + a);
+    const float w10 = z10 - (c - a), w11 = z11 - c, w12 = z12 - (c + a);
+    const float w20 = z20 - (p2 - a), w21 = z21 - p2, w22 = z22 - (p2 + a);
     const float inf = __builtin_inff();
     hf_quad q;
-    q.lo[0] = (vx0 & vy0) ? fminf(fminf(z00, z01), fminf(z10, z11)) : inf;
-    q.hi[0] = (vx0 & vy0) ? fmaxf(fmaxf(z00, z01), fmaxf(z10, z11)) : -inf;
-    q.lo[1] = (vx1 & vy0) ? fminf(fminf(z01, z02), fminf(z11, z12)) : inf;
-    q.hi[1] = (vx1 & vy0) ? fmaxf(fmaxf(z01, z02), fmaxf(z11, z12)) : -inf;
-    q.lo[2] = (vx0 & vy1) ? fminf(fminf(z10, z11), fminf(z20, z21)) : inf;
-    q.hi[2] = (vx0 & vy1) ? fmaxf(fmaxf(z10, z11), fmaxf(z20, z21)) : -inf;
-    q.lo[3] = (vx1 & vy1) ? fminf(fminf(z11, z12), fminf(z21, z22)) : inf;
-    q.hi[3] = (vx1 & vy1) ? fmaxf(fmaxf(z11, z12), fmaxf(z21, z22)) : -inf;
+    q.lo[0] = (vx0 & vy0) ? fminf(fminf(w00, w01), fminf(w10, w11)) : inf;
+    q.hi[0] = (vx0 & vy0) ? fmaxf(fmaxf(w00, w01), fmaxf(w10, w11)) : -inf;
+    q.lo[1] = (vx1 & vy0) ? fminf(fminf(w01, w02), fminf(w11, w12)) : inf;
+    q.hi[1] = (vx1 & vy0) ? fmaxf(fmaxf(w01, w02), fmaxf(w11, w12)) : -inf;
+    q.lo[2] = (vx0 & vy1) ? fminf(fminf(w10, w11), fminf(w20, w21)) : inf;
+    q.hi[2] = (vx0 & vy1) ? fmaxf(fmaxf(w10, w11), fmaxf(w20, w21)) : -inf;
+    q.lo[3] = (vx1 & vy1) ? fminf(fminf(w11, w12), fminf(w21, w22)) : inf;
+    q.hi[3] = (vx1 & vy1) ? fmaxf(fmaxf(w11, w12), fmaxf(w21, w22)) : -inf;
+    float gz, dz, mz;
+    shear_line(f, rs, fx, fy, a, b, c, __builtin_fabsf(a) + __builtin_fabsf(b), fX + 1.f, fY + 1.f, gz, dz, mz);
+    mz += 1e-6f * (__builtin_fabsf(c) + __builtin_fabsf(a) + __builtin_fabsf(b)); // rounding of the w's
     float tent[4];
-    return child_mask(r, fX, fY, 1.f, q, thi, tent);
+    return child_mask(r, fX, fY, 1.f, q, gz, dz, mz, thi, tent);
 }
 
 // actual-child mask -> order-space child mask (bit k = bit (k ^ flip))
@@ -270,12 +342,18 @@ __device__ __forceinline__ void load_children(const float2 *__restrict__ mip, in
 // data source of the per-lane subtree walk: heights + mips straight from global memory (L1/L2)
 struct hf_src_global {
     const float2 *__restrict__ mip;
+    const float4 *__restrict__ shear;
     const float *__restrict__ h;
     int top, W;
     __device__ __forceinline__ void children(int L, uint32_t ix, uint32_t iy, hf_quad &q) const {
         load_children(mip, top, L, ix, iy, q);
     }
     __device__ __forceinline__ float height(int i, int j) const { return h[(size_t) i * W + j]; }
+    // sheared record of node (ix,iy) of level L, 2 <= L <= HF_SHEAR_TOP
+    __device__ __forceinline__ const float4 *sheared(int L, uint32_t ix, uint32_t iy) const {
+        const uint32_t k = (uint32_t) (top - L);
+        return shear + (size_t) (hf_depth_off((int) k) - 1u + (iy << k) + ix) * 3;
+    }
 };
 
 // Per-lane depth-first walk of the subtree rooted at order-space node (X0,Y0) of level L0 >= 1
@@ -290,26 +368,16 @@ __device__ __forceinline__ bool walk_subtree(const hf_dev_field &f, const Src &s
 ) {
     auto loadh = [&src](int i, int j) { return src.height(i, j); };
     bool hit_any = false, fin = false, pblk = false;
-    uint32_t X = X0, Y = Y0, cur = 0, pend = 0;
-    uint64_t stk = 0; // 4 bits per level below L0; L0 can be the root of a 2^15-cell grid (incoherent waves)
-    int L = L0, pc0 = 0, pr0 = 0;
+    // start one level above the subtree root: a virtual parent whose only pending child is the root
+    uint32_t X = X0 >> 1, Y = Y0 >> 1, cur = 1u << ((X0 & 1u) | ((Y0 & 1u) << 1)), pend = 0;
+    uint64_t stk = 0; // 4 bits per level from L0 down; L0 can be the root of a 2^15-cell grid (incoherent waves)
+    int L = L0 + 1, pc0 = 0, pr0 = 0;
     float pfx = 0.f, pfy = 0.f; // order-space origin of the parked block
-    if (L0 == 1) { // the root is itself a level-1 node: one block, no walk
-        pc0 = (int) (2u * (X0 ^ (fxm >> 1))); pr0 = (int) (2u * (Y0 ^ (fym >> 1)));
-        pfx = (float) (2u * X0); pfy = (float) (2u * Y0);
-        pblk = true; fin = true;
-    } else {
-        hf_quad q;
-        src.children(L, X ^ (fxm >> L), Y ^ (fym >> L), q);
-        const float S = (float) (1u << (L - 1));
-        float tent[4];
-        cur = to_order(child_mask(r, (float) X * (S + S), (float) Y * (S + S), S, q, thi, tent), fx, fy);
-    }
     for (;;) {
         // ---- walk until this lane reaches a level-1 node (parks on it) or has exhausted the subtree ----
         while (!fin && !pblk) {
             WCOUNT(3);
-            while (cur == 0u && L < L0) { // node exhausted: pop
+            while (cur == 0u && L <= L0) { // node exhausted: pop
                 cur = (uint32_t) stk & 15u; stk >>= 4;
                 X >>= 1; Y >>= 1; ++L;
             }
@@ -330,17 +398,29 @@ __device__ __forceinline__ bool walk_subtree(const hf_dev_field &f, const Src &s
             WCOUNT(5);
             stk = (stk << 4) | (uint64_t) cur;
             X = cx; Y = cy; --L;
+            // the four children of (X,Y,L): sheared bounds on the fine levels, min/max boxes above
+            const float Sc = 0.5f * S;
+            const uint32_t ix = X ^ (fxm >> L), iy = Y ^ (fym >> L);
             hf_quad q;
-            src.children(L, X ^ (fxm >> L), Y ^ (fym >> L), q);
-            const float Sc = (float) (1u << (L - 1));
+            float gz = r.gz, dz = r.dz, mz = r.mz;
+            if (L <= HF_SHEAR_TOP) {
+                const float4 *rec = src.sheared(L, ix, iy);
+                const float4 pl = rec[0], q01 = rec[1], q23 = rec[2];
+                q.lo[0] = q01.x; q.hi[0] = q01.y; q.lo[1] = q01.z; q.hi[1] = q01.w;
+                q.lo[2] = q23.x; q.hi[2] = q23.y; q.lo[3] = q23.z; q.hi[3] = q23.w;
+                shear_line(f, rs, fx, fy, pl.x, pl.y, pl.z, pl.w, __builtin_fmaf((float) X, S, Sc),
+                           __builtin_fmaf((float) Y, S, Sc), gz, dz, mz);
+            } else {
+                src.children(L, ix, iy, q);
+            }
             float tent[4];
-            cur = to_order(child_mask(r, (float) X * (Sc + Sc), (float) Y * (Sc + Sc), Sc, q, thi, tent), fx, fy);
+            cur = to_order(child_mask(r, (float) X * S, (float) Y * S, Sc, q, gz, dz, mz, thi, tent), fx, fy);
         }
         if (__ballot(pblk) == 0ull) break; // every lane is done
         // ---- parked blocks: 3x3 heights -> candidate cells, all parked lanes together ----
         if (pblk) {
             WCOUNT(4);
-            pend = block_cells(f, r, pc0, pr0, pfx, pfy, thi, loadh);
+            pend = block_cells(f, rs, fx, fy, pc0, pr0, pfx, pfy, thi, loadh);
             pblk = false;
         }
         // ---- candidate cells, one per lane per round ----
@@ -412,7 +492,7 @@ __device__ __forceinline__ void walk_packet(const hf_dev_field &f, const hf_lds_
             WCOUNT(2);
             const int L0 = L - 1;
             hf_src_global src;
-            src.mip = f.mip; src.h = f.h; src.top = f.top; src.W = f.W;
+            src.mip = f.mip; src.shear = f.shear; src.h = f.h; src.top = f.top; src.W = f.W;
             if (mine) {
                 // per-lane mirror flags: equal to (fx,fy) in a coherent wave, arbitrary otherwise
                 const uint32_t lfxm = rs.fx ? ((1u << top) - 1u) : 0u, lfym = rs.fy ? ((1u << top) - 1u) : 0u;
@@ -450,7 +530,7 @@ __device__ __forceinline__ void walk_packet(const hf_dev_field &f, const hf_lds_
             }
             const float S = (float) (1u << (L - 1));
             float tent[4];
-            ml = child_mask(r, (float) X * (S + S), (float) Y * (S + S), S, q, thi, tent);
+            ml = child_mask(r, (float) X * (S + S), (float) Y * (S + S), S, q, r.gz, r.dz, r.mz, thi, tent);
             uint32_t ma = 0;
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) ma |= (__ballot((ml >> jj) & 1u) != 0ull) ? (1u << jj) : 0u;
