@@ -468,6 +468,9 @@ __device__ __forceinline__ void walk_packet(const hf_dev_field &f, const hf_lds_
     int L = top + 1;                 // virtual node above the root whose only child (k = 0) is the root
     uint64_t stk = 0;
     uint32_t ml = alive ? 1u : 0u;   // per-lane overlap mask (ACTUAL child numbering) of the current node
+#ifdef HF_TSTATS
+    long long tsub = 0;
+#endif
 #ifdef HF_WSTATS
     if ((threadIdx.x & 63u) < 8u) wcnt_base()[threadIdx.x & 63u] = 0u;
 #endif
@@ -493,6 +496,9 @@ __device__ __forceinline__ void walk_packet(const hf_dev_field &f, const hf_lds_
             const int L0 = L - 1;
             hf_src_global src;
             src.mip = f.mip; src.shear = f.shear; src.h = f.h; src.top = f.top; src.W = f.W;
+#ifdef HF_TSTATS
+            const long long ts0 = clock64();
+#endif
             if (mine) {
                 // per-lane mirror flags: equal to (fx,fy) in a coherent wave, arbitrary otherwise
                 const uint32_t lfxm = rs.fx ? ((1u << top) - 1u) : 0u, lfym = rs.fy ? ((1u << top) - 1u) : 0u;
@@ -500,6 +506,9 @@ __device__ __forceinline__ void walk_packet(const hf_dev_field &f, const hf_lds_
                 );
                 if (ANY && h) thi = -1.f;
             }
+#ifdef HF_TSTATS
+            tsub += clock64() - ts0;
+#endif
             continue;
         }
         // inner node (cx,cy) of level L-1.  Its mask bit may predate the hits found since: skip it when no
@@ -538,6 +547,9 @@ __device__ __forceinline__ void walk_packet(const hf_dev_field &f, const hf_lds_
         }
     }
 done:;
+#ifdef HF_TSTATS // diagnostic build (scripts/tstats.py): cycles spent in the per-lane walks of this batch
+    if (alive) { best.hit = true; best.u = (float) tsub; }
+#endif
 #ifdef HF_WSTATS
     if (alive) { const uint32_t *c = wcnt_base(); best.hit = true; best.t = (float) c[0] + 1024.f * (float) c[1] + 1048576.f * (float) c[2];
         best.u = (float) c[3] + 4096.f * (float) c[4]; best.v = (float) c[5] + 4096.f * (float) c[6]; }
@@ -627,6 +639,9 @@ __global__ __launch_bounds__(HF_BLOCK, 4) void hf_trace_kernel(hf_dev_field f, s
             hf_hit best;
             best.hit = false; best.t = __builtin_inff(); best.u = 0.f; best.v = 0.f; best.prim = 0u;
             const bool act = valid && (active ? (active[i] != 0) : true);
+#ifdef HF_TSTATS
+            const long long tb0 = clock64();
+#endif
             hf_ray_state rs;
             const bool alive = act && setup_ray(f, s.node[1], o, d, maxt, rs);
             const uint64_t am = __ballot(alive);
@@ -642,7 +657,13 @@ __global__ __launch_bounds__(HF_BLOCK, 4) void hf_trace_kernel(hf_dev_field f, s
                                   (__builtin_fabsf(ux * uy0 - uy * ux0) <= 0.05f * __builtin_fabsf(ux * uy0));
                 const bool coherent = __ballot(alive && !near) == 0ull;
                 // incoherent wave: the shared walk degenerates to handing the root to every live lane
+#ifdef HF_TSTATS
+                const long long tb1 = clock64();
+#endif
                 walk_packet<MODE == 1>(f, s, rs, alive, coherent, fx0, fy0, best);
+#ifdef HF_TSTATS
+                if (alive) { best.t = (float) (clock64() - tb0); best.v = (float) (tb1 - tb0); }
+#endif
             }
             if (!valid) continue;
             if (MODE == 1) {
