@@ -147,7 +147,6 @@ __device__ __forceinline__ uint32_t *wcnt_base() {
 struct hf_trav {
     float gxm, gxp, gym, gyp; // origin x,y  +/- the xy margin m
     float gz, dz, idx, idy, mz;
-    float nx0, nx1, ny0, ny1; // order-space column/row (0 = near half, 1 = far half) of ACTUAL child column/row 0, 1
 };
 
 // four cells as (min,max) boxes in ACTUAL order j = 2*jy + jx
@@ -161,14 +160,17 @@ struct hf_quad {
 // for min/max boxes, the sheared height for sheared bounds.  Direction is >= 0 in order space, so a box's entry planes are its low
 // faces and its exit planes its high faces; v_max3/v_min3 drop the NaN of 0*inf (origin of an
 // axis-parallel ray exactly on a face plane).
-__device__ __forceinline__ uint32_t child_mask(const hf_trav &r, float fX, float fY, float S, const hf_quad &q,
-                                               float gz, float dz, float mz, float thi, float tent[4]) {
+__device__ __forceinline__ uint32_t child_mask(const hf_trav &r, bool fx, bool fy, float fX, float fY, float S,
+                                               const hf_quad &q, float gz, float dz, float mz, float thi,
+                                               float tent[4]) {
     const float ex = fX - r.gxm, lx = fX + S - r.gxp; // entry / exit plane offsets of order column 0
     const float ey = fY - r.gym, ly = fY + S - r.gyp;
-    const float x0lo = __builtin_fmaf(S, r.nx0, ex) * r.idx, x0hi = __builtin_fmaf(S, r.nx0, lx) * r.idx;
-    const float x1lo = __builtin_fmaf(S, r.nx1, ex) * r.idx, x1hi = __builtin_fmaf(S, r.nx1, lx) * r.idx;
-    const float y0lo = __builtin_fmaf(S, r.ny0, ey) * r.idy, y0hi = __builtin_fmaf(S, r.ny0, ly) * r.idy;
-    const float y1lo = __builtin_fmaf(S, r.ny1, ey) * r.idy, y1hi = __builtin_fmaf(S, r.ny1, ly) * r.idy;
+    // order-space offset of ACTUAL child column / row 0 and 1 (a mirrored axis swaps near and far half)
+    const float sx0 = fx ? S : 0.f, sx1 = S - sx0, sy0 = fy ? S : 0.f, sy1 = S - sy0;
+    const float x0lo = (ex + sx0) * r.idx, x0hi = (lx + sx0) * r.idx;
+    const float x1lo = (ex + sx1) * r.idx, x1hi = (lx + sx1) * r.idx;
+    const float y0lo = (ey + sy0) * r.idy, y0hi = (ly + sy0) * r.idy;
+    const float y1lo = (ey + sy1) * r.idy, y1hi = (ly + sy1) * r.idy;
     uint32_t m = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -257,8 +259,6 @@ __device__ __forceinline__ bool setup_ray(const hf_dev_field &f, float2 zr, v3 o
     r.gxm = gx + m; r.gxp = gx - m; r.gym = gy + m; r.gyp = gy - m;
     float thi = tout - tin;
     thi = thi + thi * 1e-6f + 1e-30f;
-    r.nx0 = fx ? 1.f : 0.f; r.nx1 = 1.f - r.nx0;
-    r.ny0 = fy ? 1.f : 0.f; r.ny1 = 1.f - r.ny0;
 
     rs.tin = tin; rs.thi = thi; rs.gx = gx; rs.gy = gy; rs.m = m; rs.fx = fx; rs.fy = fy;
     return true;
@@ -319,7 +319,7 @@ __device__ __forceinline__ uint32_t block_cells(const hf_dev_field &f, const hf_
     shear_line(f, rs, fx, fy, a, b, c, __builtin_fabsf(a) + __builtin_fabsf(b), fX + 1.f, fY + 1.f, gz, dz, mz);
     mz += 1e-6f * (__builtin_fabsf(c) + __builtin_fabsf(a) + __builtin_fabsf(b)); // rounding of the w's
     float tent[4];
-    return child_mask(r, fX, fY, 1.f, q, gz, dz, mz, thi, tent);
+    return child_mask(r, fx, fy, fX, fY, 1.f, q, gz, dz, mz, thi, tent);
 }
 
 // actual-child mask -> order-space child mask (bit k = bit (k ^ flip))
@@ -414,7 +414,7 @@ __device__ __forceinline__ bool walk_subtree(const hf_dev_field &f, const Src &s
                 src.children(L, ix, iy, q);
             }
             float tent[4];
-            cur = to_order(child_mask(r, (float) X * S, (float) Y * S, Sc, q, gz, dz, mz, thi, tent), fx, fy);
+            cur = to_order(child_mask(r, fx, fy, (float) X * S, (float) Y * S, Sc, q, gz, dz, mz, thi, tent), fx, fy);
         }
         if (__ballot(pblk) == 0ull) break; // every lane is done
         // ---- parked blocks: 3x3 heights -> candidate cells, all parked lanes together ----
@@ -539,7 +539,7 @@ __device__ __forceinline__ void walk_packet(const hf_dev_field &f, const hf_lds_
             }
             const float S = (float) (1u << (L - 1));
             float tent[4];
-            ml = child_mask(r, (float) X * (S + S), (float) Y * (S + S), S, q, r.gz, r.dz, r.mz, thi, tent);
+            ml = child_mask(r, fx, fy, (float) X * (S + S), (float) Y * (S + S), S, q, r.gz, r.dz, r.mz, thi, tent);
             uint32_t ma = 0;
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) ma |= (__ballot((ml >> jj) & 1u) != 0ull) ? (1u << jj) : 0u;
@@ -572,11 +572,10 @@ struct hf_si_dev {
 // record stores are write-once streams (72 B/ray): non-temporal, so that they do not push the mip
 // and height lines of concurrently traversing waves out of L2
 __device__ __forceinline__ void st(float *p, size_t i, float v) { if (p) __builtin_nontemporal_store(v, &p[i]); }
-__device__ __forceinline__ void st3(float *const p[3], size_t i, v3 v) {
-    st(p[0], i, v.x); st(p[1], i, v.y); st(p[2], i, v.z);
-}
+#define st3(p, i, v) do { st((p)[0], i, (v).x); st((p)[1], i, (v).y); st((p)[2], i, (v).z); } while (0)
 
-__device__ __forceinline__ void store_si(const hf_si_dev &out, size_t i, const hf_si_rec &si, uint32_t flags) {
+template <typename SiDev>
+__device__ __forceinline__ void store_si(const SiDev &out, size_t i, const hf_si_rec &si, uint32_t flags) {
     st(out.t, i, si.t);
     st3(out.p, i, si.p);
     st3(out.n, i, si.n);
@@ -605,11 +604,27 @@ __device__ __forceinline__ void miss_si(hf_si_rec &si, v3 d, uint32_t flags) {
 // Persistent waves: every wave pulls HF_GRAB consecutive rays at a time from a global
 // counter (zeroed on the stream before the launch), so expensive image regions are
 // spread over all CUs whatever their position in the wavefront.
+// the one kernel argument (kernarg segment offset 0)
+struct hf_trace_args {
+    hf_dev_field f;
+    size_t n;
+    hf_rays_dev rays;
+    const uint8_t *active;
+    hf_pi_dev pi;
+    uint8_t *hit_out;
+    hf_si_dev sio;
+    uint32_t flags;
+    unsigned long long *counter;
+};
+
 template <int MODE>
-__global__ __launch_bounds__(HF_BLOCK, 4) void hf_trace_kernel(hf_dev_field f, size_t n, hf_rays_dev rays,
-                                                            const uint8_t *__restrict__ active, hf_pi_dev pi,
-                                                            uint8_t *__restrict__ hit_out, hf_si_dev sio,
-                                                            uint32_t flags, unsigned long long *counter) {
+__global__ __launch_bounds__(HF_BLOCK, 4) void hf_trace_kernel(hf_trace_args a) {
+    const hf_dev_field &f = a.f;
+    const size_t n = a.n;
+    const hf_rays_dev &rays = a.rays;
+    const uint8_t *__restrict__ active = a.active;
+    const uint32_t flags = a.flags;
+    unsigned long long *counter = a.counter;
     __shared__ hf_lds_mips s;
     stage_mips(f, s);
     const unsigned lane = threadIdx.x & 63u;
@@ -666,9 +681,18 @@ __global__ __launch_bounds__(HF_BLOCK, 4) void hf_trace_kernel(hf_dev_field f, s
 #endif
             }
             if (!valid) continue;
+            // The ~30 output pointers are read from the kernarg segment here, where they are used: kept in
+            // scalar registers across the walk they get spilled into vector-register lanes, and every
+            // conditional store then pays vector instructions to fetch them back.
+            const __attribute__((address_space(4))) hf_trace_args *ka =
+                (const __attribute__((address_space(4))) hf_trace_args *) __builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(ka)); // opaque: keeps the loads below out of the loop header
             if (MODE == 1) {
+                uint8_t *hit_out = ka->hit_out;
                 hit_out[i] = best.hit ? 1 : 0;
             } else {
+                hf_pi_dev pi;
+                pi.t = ka->pi.t; pi.u = ka->pi.u; pi.v = ka->pi.v; pi.prim = ka->pi.prim;
                 if (pi.t) pi.t[i] = best.hit ? best.t : __builtin_inff();
                 if (pi.u) pi.u[i] = best.hit ? best.u : 0.f;
                 if (pi.v) pi.v[i] = best.hit ? best.v : 0.f;
@@ -677,7 +701,7 @@ __global__ __launch_bounds__(HF_BLOCK, 4) void hf_trace_kernel(hf_dev_field f, s
                     hf_si_rec si;
                     if (best.hit) compute_si(f, o, d, best.t, best.u, best.v, best.prim, flags, si);
                     else          miss_si(si, d, flags);
-                    store_si(sio, i, si, flags);
+                    store_si(ka->sio, i, si, flags);
                 }
             }
         }
@@ -724,12 +748,15 @@ void hf_launch_trace(int mode, const hf_dev_field &f, size_t n, const hf_rays_t 
     size_t waves = (n + HF_GRAB - 1) / HF_GRAB, blocks = (waves + 3) / 4;
     if (blocks > 256 * 4) blocks = 256 * 4; // 4 resident workgroups per CU (128 VGPRs)
     const dim3 grid((unsigned) blocks), block(HF_BLOCK);
+    hf_trace_args a;
+    a.f = f; a.n = n; a.rays = r; a.active = active; a.pi = p; a.hit_out = hit; a.sio = sd; a.flags = flags;
+    a.counter = counter;
     if (mode == 0)
-        hipLaunchKernelGGL(hf_trace_kernel<0>, grid, block, 0, stream, f, n, r, active, p, hit, sd, flags, counter);
+        hipLaunchKernelGGL(hf_trace_kernel<0>, grid, block, 0, stream, a);
     else if (mode == 1)
-        hipLaunchKernelGGL(hf_trace_kernel<1>, grid, block, 0, stream, f, n, r, active, p, hit, sd, flags, counter);
+        hipLaunchKernelGGL(hf_trace_kernel<1>, grid, block, 0, stream, a);
     else
-        hipLaunchKernelGGL(hf_trace_kernel<2>, grid, block, 0, stream, f, n, r, active, p, hit, sd, flags, counter);
+        hipLaunchKernelGGL(hf_trace_kernel<2>, grid, block, 0, stream, a);
 }
 
 // ---------------------------------------------------------------------------------
