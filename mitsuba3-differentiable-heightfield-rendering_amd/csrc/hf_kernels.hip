@@ -617,12 +617,21 @@ struct hf_trace_args {
     unsigned long long *counter;
 };
 
+// member-wise copy out of the kernarg segment (constant address space)
+__device__ __forceinline__ hf_dev_field load_field(const __attribute__((address_space(4))) hf_dev_field *p) {
+    hf_dev_field f;
+    f.h = p->h; f.mip = p->mip; f.shear = p->shear;
+    f.W = p->W; f.H = p->H; f.top = p->top;
+    f.s = p->s; f.sx = p->sx; f.sy = p->sy; f.iu = p->iu; f.iv = p->iv; f.flip = p->flip;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) { f.to_world[k] = p->to_world[k]; f.to_object[k] = p->to_object[k]; }
+    return f;
+}
+
 template <int MODE>
 __global__ __launch_bounds__(HF_BLOCK, 4) void hf_trace_kernel(hf_trace_args a) {
     const hf_dev_field &f = a.f;
     const size_t n = a.n;
-    const hf_rays_dev &rays = a.rays;
-    const uint8_t *__restrict__ active = a.active;
     const uint32_t flags = a.flags;
     unsigned long long *counter = a.counter;
     __shared__ hf_lds_mips s;
@@ -648,17 +657,28 @@ __global__ __launch_bounds__(HF_BLOCK, 4) void hf_trace_kernel(hf_trace_args a) 
             if (base + sub >= n) break; // wave-uniform
             const bool valid = i_raw < n;
             const size_t i = valid ? i_raw : n - 1;
-            const v3 o = mk3(rays.o[0][i], rays.o[1][i], rays.o[2][i]);
-            const v3 d = mk3(rays.d[0][i], rays.d[1][i], rays.d[2][i]);
-            const float maxt = rays.maxt[i];
+            // Pointers and constants that are only needed before or after the walk are read from the kernarg
+            // segment where they are used: held in scalar registers across the walk they get spilled into
+            // vector-register lanes, and fetching them back costs vector instructions.
+            const __attribute__((address_space(4))) hf_trace_args *ka =
+                (const __attribute__((address_space(4))) hf_trace_args *) __builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(ka)); // opaque: keeps these loads inside the loop body
+            const v3 o = mk3(ka->rays.o[0][i], ka->rays.o[1][i], ka->rays.o[2][i]);
+            const v3 d = mk3(ka->rays.d[0][i], ka->rays.d[1][i], ka->rays.d[2][i]);
+            const float maxt = ka->rays.maxt[i];
             hf_hit best;
             best.hit = false; best.t = __builtin_inff(); best.u = 0.f; best.v = 0.f; best.prim = 0u;
+            const uint8_t *active = ka->active;
             const bool act = valid && (active ? (active[i] != 0) : true);
 #ifdef HF_TSTATS
             const long long tb0 = clock64();
 #endif
             hf_ray_state rs;
-            const bool alive = act && setup_ray(f, s.node[1], o, d, maxt, rs);
+            bool alive;
+            {
+                const hf_dev_field f0 = load_field(&ka->f); // to_object etc.
+                alive = act && setup_ray(f0, s.node[1], o, d, maxt, rs);
+            }
             const uint64_t am = __ballot(alive);
             if (am != 0ull) {
                 // coherent wave?  equal direction signs, entry points and directions close to the first live lane's
@@ -681,12 +701,7 @@ __global__ __launch_bounds__(HF_BLOCK, 4) void hf_trace_kernel(hf_trace_args a) 
 #endif
             }
             if (!valid) continue;
-            // The ~30 output pointers are read from the kernarg segment here, where they are used: kept in
-            // scalar registers across the walk they get spilled into vector-register lanes, and every
-            // conditional store then pays vector instructions to fetch them back.
-            const __attribute__((address_space(4))) hf_trace_args *ka =
-                (const __attribute__((address_space(4))) hf_trace_args *) __builtin_amdgcn_kernarg_segment_ptr();
-            asm volatile("" : "+s"(ka)); // opaque: keeps the loads below out of the loop header
+            asm volatile("" : "+s"(ka)); // the ~30 output pointers: loaded here, not before the walk
             if (MODE == 1) {
                 uint8_t *hit_out = ka->hit_out;
                 hit_out[i] = best.hit ? 1 : 0;
@@ -699,7 +714,10 @@ __global__ __launch_bounds__(HF_BLOCK, 4) void hf_trace_kernel(hf_trace_args a) 
                 if (pi.prim) pi.prim[i] = best.hit ? best.prim : 0u;
                 if (MODE == 2) {
                     hf_si_rec si;
-                    if (best.hit) compute_si(f, o, d, best.t, best.u, best.v, best.prim, flags, si);
+                    if (best.hit) {
+                        const hf_dev_field fl = load_field(&ka->f); // to_world etc.: not held across the walk
+                        compute_si(fl, o, d, best.t, best.u, best.v, best.prim, flags, si);
+                    }
                     else          miss_si(si, d, flags);
                     store_si(ka->sio, i, si, flags);
                 }
