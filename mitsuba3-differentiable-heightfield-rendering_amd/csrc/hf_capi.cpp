@@ -117,6 +117,10 @@ extern "C" int hf_create(const hf_desc_t *desc, hf_field_t **out) {
     while ((1 << top) < cw || (1 << top) < ch) ++top;
     if (top < 1) top = 1;
     if (top > 15) { free(hf); return fail(HF_EINVAL, "hf_create: grid too large (more than 32768 cells per side)"); }
+    if ((size_t) d.W * (size_t) d.H > ((size_t) 1 << 30)) { // the kernels address heights with 32-bit byte offsets
+        free(hf);
+        return fail(HF_EINVAL, "hf_create: grid too large (more than 2^30 vertices)");
+    }
     d.top = top;
     const size_t off = hf_depth_off(top); // (4^top - 1)/3 nodes, depths 0..top-1
     hf->mip_nodes = off;

@@ -348,7 +348,18 @@ struct hf_src_global {
     __device__ __forceinline__ void children(int L, uint32_t ix, uint32_t iy, hf_quad &q) const {
         load_children(mip, top, L, ix, iy, q);
     }
-    __device__ __forceinline__ float height(int i, int j) const { return h[(size_t) i * W + j]; }
+    // 32-bit byte offset from the uniform base (one scalar-base load, no 64-bit vector address maths);
+    // hf_create limits the grid to 2^30 vertices
+    __device__ __forceinline__ float height(int i, int j) const {
+        const uint32_t off = ((uint32_t) i * (uint32_t) W + (uint32_t) j) << 2;
+        return *(const float *) ((const char *) h + off);
+    }
+    // the two 16-byte halves (children 0,1 / 2,3) of the child boxes of inner node (ix,iy) of level L
+    __device__ __forceinline__ void children_ptrs(int L, uint32_t ix, uint32_t iy, const float4 *&a, const float4 *&b) const {
+        const uint32_t kd = (uint32_t) (top - (L - 1));
+        const uint32_t base = hf_depth_off((int) kd) + ((2u * iy) << kd) + 2u * ix;
+        a = (const float4 *) (mip + base); b = (const float4 *) (mip + base + (1u << kd));
+    }
     // sheared record of node (ix,iy) of level L, 2 <= L <= HF_SHEAR_TOP
     __device__ __forceinline__ const float4 *sheared(int L, uint32_t ix, uint32_t iy) const {
         const uint32_t k = (uint32_t) (top - L);
@@ -403,15 +414,20 @@ __device__ __forceinline__ bool walk_subtree(const hf_dev_field &f, const Src &s
             const uint32_t ix = X ^ (fxm >> L), iy = Y ^ (fym >> L);
             hf_quad q;
             float gz = r.gz, dz = r.dz, mz = r.mz;
+            const float4 *pa, *pb; // the child ranges are two 16-byte loads on either path
             if (L <= HF_SHEAR_TOP) {
                 const float4 *rec = src.sheared(L, ix, iy);
-                const float4 pl = rec[0], q01 = rec[1], q23 = rec[2];
-                q.lo[0] = q01.x; q.hi[0] = q01.y; q.lo[1] = q01.z; q.hi[1] = q01.w;
-                q.lo[2] = q23.x; q.hi[2] = q23.y; q.lo[3] = q23.z; q.hi[3] = q23.w;
+                const float4 pl = rec[0];
+                pa = rec + 1; pb = rec + 2;
                 shear_line(f, rs, fx, fy, pl.x, pl.y, pl.z, pl.w, __builtin_fmaf((float) X, S, Sc),
                            __builtin_fmaf((float) Y, S, Sc), gz, dz, mz);
             } else {
-                src.children(L, ix, iy, q);
+                src.children_ptrs(L, ix, iy, pa, pb);
+            }
+            {
+                const float4 q01 = *pa, q23 = *pb;
+                q.lo[0] = q01.x; q.hi[0] = q01.y; q.lo[1] = q01.z; q.hi[1] = q01.w;
+                q.lo[2] = q23.x; q.hi[2] = q23.y; q.lo[3] = q23.z; q.hi[3] = q23.w;
             }
             float tent[4];
             cur = to_order(child_mask(r, fx, fy, (float) X * S, (float) Y * S, Sc, q, gz, dz, mz, thi, tent), fx, fy);
