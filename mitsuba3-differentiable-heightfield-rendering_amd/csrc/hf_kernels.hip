@@ -615,9 +615,9 @@ __device__ __forceinline__ void miss_si(hf_si_rec &si, v3 d, uint32_t flags) {
     si.wi = neg3(d);
 }
 
-#define HF_GRAB 512 // rays a wave takes from the work counter per fetch
+#define HF_GRAB 512 // most rays a wave takes from the work counter per fetch (hf_grab_for)
 
-// Persistent waves: every wave pulls HF_GRAB consecutive rays at a time from a global
+// Persistent waves: every wave pulls `grab` consecutive rays at a time from a global
 // counter (zeroed on the stream before the launch), so expensive image regions are
 // spread over all CUs whatever their position in the wavefront.
 // the one kernel argument (kernarg segment offset 0)
@@ -630,6 +630,7 @@ struct hf_trace_args {
     uint8_t *hit_out;
     hf_si_dev sio;
     uint32_t flags;
+    uint32_t grab; // rays per fetch, a multiple of 64
     unsigned long long *counter;
 };
 
@@ -657,16 +658,17 @@ __global__ __launch_bounds__(HF_BLOCK, 4) void hf_trace_kernel(hf_trace_args a) 
     // its back.  Rays that miss the bound only stream (memory/atomic-bound), rays that traverse are
     // issue-bound: in rendered wavefronts the two come in large contiguous regions, and two fronts
     // let them overlap in time instead of running one after the other.
-    const unsigned long long n_grabs = (n + HF_GRAB - 1) / HF_GRAB;
+    const unsigned grab = a.grab;
+    const unsigned long long n_grabs = (n + grab - 1) / grab;
     for (;;) {
         unsigned long long g = 0;
         if (lane == 0) g = atomicAdd(counter, 1ull);
         g = ((unsigned long long) (uint32_t) __builtin_amdgcn_readfirstlane((int) (g >> 32)) << 32) |
             (unsigned long long) (uint32_t) __builtin_amdgcn_readfirstlane((int) (g & 0xffffffffull));
         if (g >= n_grabs) break;
-        const unsigned long long base = ((g & 1ull) ? (n_grabs >> 1) - 1ull - (g >> 1) : (n_grabs >> 1) + (g >> 1)) * HF_GRAB;
+        const unsigned long long base = ((g & 1ull) ? (n_grabs >> 1) - 1ull - (g >> 1) : (n_grabs >> 1) + (g >> 1)) * grab;
 #pragma unroll 1
-        for (unsigned sub = 0; sub < HF_GRAB; sub += 64) {
+        for (unsigned sub = 0; sub < grab; sub += 64) {
             // all 64 lanes stay in the loop body (the shared walk relies on whole-wave ballots);
             // lanes past the end of the wavefront re-read the last ray and store nothing
             const size_t i_raw = base + sub + lane;
@@ -768,6 +770,17 @@ static hf_si_dev to_dev(const hf_si_t *s) {
     return d;
 }
 
+// Rays per fetch: 512 for big wavefronts (a single counter serves ~80 fetches/us, which caps the rate of
+// rays that only stream), fewer for small ones so that every resident wave gets several fetches --
+// a fetch of 512 traversing rays is ~0.4 ms of work, the whole launch for a 4 M-ray wavefront.
+static uint32_t hf_grab_for(size_t n) {
+    const size_t resident = 256 * 4 * 4;         // waves the launch keeps on the chip
+    size_t g = (n / (resident * 4) + 63) / 64 * 64; // ~4 fetches per wave
+    if (g < 64) g = 64;
+    if (g > HF_GRAB) g = HF_GRAB;
+    return (uint32_t) g;
+}
+
 void hf_launch_trace(int mode, const hf_dev_field &f, size_t n, const hf_rays_t *rays, const uint8_t *active,
                      const hf_pi_t *pi, uint8_t *hit, const hf_si_t *si, uint32_t flags, unsigned long long *counter,
                      hipStream_t stream) {
@@ -779,12 +792,13 @@ void hf_launch_trace(int mode, const hf_dev_field &f, size_t n, const hf_rays_t 
     memset(&sd, 0, sizeof(sd));
     if (si) sd = to_dev(si);
     const hf_rays_dev r = to_dev(rays);
-    size_t waves = (n + HF_GRAB - 1) / HF_GRAB, blocks = (waves + 3) / 4;
+    const uint32_t grab = hf_grab_for(n);
+    size_t waves = (n + grab - 1) / grab, blocks = (waves + 3) / 4;
     if (blocks > 256 * 4) blocks = 256 * 4; // 4 resident workgroups per CU (128 VGPRs)
     const dim3 grid((unsigned) blocks), block(HF_BLOCK);
     hf_trace_args a;
     a.f = f; a.n = n; a.rays = r; a.active = active; a.pi = p; a.hit_out = hit; a.sio = sd; a.flags = flags;
-    a.counter = counter;
+    a.counter = counter; a.grab = grab;
     if (mode == 0)
         hipLaunchKernelGGL(hf_trace_kernel<0>, grid, block, 0, stream, a);
     else if (mode == 1)
