@@ -139,14 +139,16 @@ typedef struct hf_si_grad {
 
 /* Replaces: plugin construction + update() (src/shapes/rectangle.cpp:83-112) and the
  * OptiX blob upload optix_prepare_geometry (rectangle.cpp:328-338).  Heights start
- * as all zero; call hf_set_heights* before tracing. */
+ * as all zero; call hf_set_heights* before tracing.  Limits: width, height >= 2
+ * (bitmap.cpp:280-283), at most 32768 cells per side and 2^30 vertices (HF_EINVAL beyond). */
 int hf_create(const hf_desc_t *desc, hf_field_t **out);
 int hf_destroy(hf_field_t *hf);
 
 /* Replaces: parameters_changed({"heightfield"}) (pattern rectangle.cpp:131-142,
  * tensor form src/textures/bitmap.cpp:272-286) + the accel rebuild it triggers
  * (src/render/scene.cpp:343-385): copies width*height floats (row-major, row 0 at
- * object y=-1) from DEVICE memory and rebuilds the min/max mip pyramid, all on `stream`. */
+ * object y=-1) from DEVICE memory and rebuilds the acceleration data (min/max mip pyramid and the
+ * sheared bounds of its fine levels), all on `stream`. */
 int hf_set_heights(hf_field_t *hf, const float *d_heights, hf_stream_t stream);
 /* same from HOST memory (synchronous copy) */
 int hf_set_heights_host(hf_field_t *hf, const float *h_heights, hf_stream_t stream);
