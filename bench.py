@@ -164,6 +164,9 @@ def main():
                     "avg_launch_ms": round(dom_ms, 4),
                     "fwd_ms": round(fwd_ms, 4), "adj_ms": round(adj_ms, 4),
                     "fwd_adj_frac": round(((fwd_bytes + adj_bytes) / ((fwd_ms + adj_ms) * 1e-3) / 1e9) / HBM_PEAK_GBS, 5)}
+        extras = None
+        if world == 1:
+            extras = other_launches(torch, hf_amd, _capi, lib, shape, r_s, pi_s, si_s, si, R, stream, flags)
         cpu = None
         if world == 1 and args.cpu_seconds > 0:
             cpu = cpu_baseline(args, heights.cpu().numpy(), rays, gsi, R)
@@ -175,11 +178,53 @@ def main():
                                       f"= {R} rays/GPU, forward(ray_intersect, RayFlags.All)+adjoint(dL/dheight)",
                           "rays_per_gpu": R, "hit_fraction": round(hit_frac, 4),
                           "parallelism": f"rays sharded over {world} GPU(s), 1 all-reduce of the grad texture"},
-               "roofline": roofline, "cpu_baseline": cpu}
+               "roofline": roofline, "cpu_baseline": cpu, "other_launches_ms": extras}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    return out
+
+
+def other_launches(torch, hf_amd, _capi, lib, shape, r_s, pi_s, si_s, si, R, stream, flags, iters=3):
+    """Not part of `value`: the other entry points of the path on the same wavefront, and on the incoherent
+    secondary rays of SURVEY 8d (one cosine bounce + one shadow ray per primary hit), HIP-event ms per launch."""
+    dev = si.device
+    hit8 = torch.empty(R, dtype=torch.uint8, device=dev)
+    hit_idx = torch.nonzero(torch.isfinite(si[0])).squeeze(1)
+    bounce, shadow = hf_amd.workload.secondary_rays(si[1:4][:, hit_idx], si[4:7][:, hit_idx], seed=0)
+    Rs = bounce.shape[1]
+    b_s = shape._rays_struct(bounce[0:3], bounce[3:6], bounce[6])
+    s_s = shape._rays_struct(shadow[0:3], shadow[3:6], shadow[6])
+    fn = {
+        "ray_intersect_preliminary": lambda: lib.hf_ray_intersect_preliminary(shape._h, R, C.byref(r_s), None, C.byref(pi_s), stream),
+        "ray_test": lambda: lib.hf_ray_test(shape._h, R, C.byref(r_s), None, hit8.data_ptr(), stream),
+        "compute_surface_interaction": lambda: lib.hf_compute_surface_interaction(shape._h, R, C.byref(r_s), C.byref(pi_s), flags, None, C.byref(si_s), stream),
+        "parameters_changed(mip rebuild)": lambda: (shape.parameters_changed(["heightfield"]), 0)[1],
+    }
+    out = {}
+    for name, f in fn.items():
+        _capi.check(f()); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            _capi.check(f())
+        e1.record(); torch.cuda.synchronize()
+        out[name] = round(e0.elapsed_time(e1) / iters, 4)
+    # secondary rays last: they overwrite pi / si of the primary wavefront
+    sec = {
+        "bounce_rays_ray_intersect": lambda: lib.hf_ray_intersect(shape._h, Rs, C.byref(b_s), flags, None, C.byref(pi_s), C.byref(si_s), stream),
+        "shadow_rays_ray_test": lambda: lib.hf_ray_test(shape._h, Rs, C.byref(s_s), None, hit8.data_ptr(), stream),
+    }
+    for name, f in sec.items():
+        _capi.check(f()); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            _capi.check(f())
+        e1.record(); torch.cuda.synchronize()
+        out[name] = round(e0.elapsed_time(e1) / iters, 4)
+    out["secondary_rays"] = int(Rs)
     return out
 
 
