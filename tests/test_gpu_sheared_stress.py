@@ -47,7 +47,14 @@ def _packet_rays(n_pix, rng, zmax):
     o = np.concatenate([c, np.full((1, n_pix), zmax * 0.5)]) - dirs * 2.5
     o = np.repeat(o, 64, 1) + rng.uniform(-2e-3, 2e-3, (3, n_pix * 64))
     d = np.repeat(dirs, 64, 1) * (1 + rng.uniform(-1e-3, 1e-3, (1, n_pix * 64)))
-    return np.concatenate([o, d, np.full((1, n_pix * 64), np.inf)]).astype(np.float32)
+    maxt = np.full((1, n_pix * 64), np.inf)
+    # partially dead packets: lanes with a short / negative maxt, a non-finite origin or direction
+    k = rng.uniform(size=n_pix * 64)
+    maxt[0, k < 0.10] = rng.uniform(0.5, 3.5, int((k < 0.10).sum()))
+    maxt[0, (k >= 0.10) & (k < 0.13)] = -1.0
+    o[0, (k >= 0.13) & (k < 0.15)] = np.nan
+    d[2, (k >= 0.15) & (k < 0.17)] = np.inf
+    return np.concatenate([o, d, maxt]).astype(np.float32)
 
 
 def _compare(hf, f_o, f_g, r):
