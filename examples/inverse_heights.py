@@ -6,8 +6,9 @@ A minimal direct-lighting differentiable render on top of the heightfield shape:
     primary rays (orthographic)  ->  shape.ray_intersect (HIP traversal + fused SI)
     image_k = albedo * max(0, <n, l_k>)  for K directional lights,  depth = t
     loss = sum_k |image_k - target_k|^2 + lambda |depth - depth_target|^2     (valid pixels)
-    loss.backward()  ->  HIP adjoint scatters dL/dheight;  Adam step;  shape.parameters_changed()
-        (= mip rebuild, what scene.parameters_changed does once per optimiser step, scene.cpp:343-385)
+    loss.backward()  ->  HIP adjoint scatters dL/dheight;  hf_amd.Adam.step() = hf_adam_step: Adam update on the
+        device + rebuild of the acceleration data (what params.update / scene.parameters_changed do once per
+        optimiser step, util.py:185-232, scene.cpp:343-385)
 Geometry is attached (prb-style, no silhouette reparameterisation: SURVEY 8f rank 3 is not built).
 
     python examples/inverse_heights.py [--grid 128 --film 256 --steps 100]
@@ -48,19 +49,18 @@ def run(grid=128, film=256, spp=1, steps=100, lr=0.02, device="cuda", verbose=Tr
         tgt_shade, tgt_depth, tgt_valid = render(target, ray, lights)
     shape = hf_amd.Heightfield(heightfield=torch.full_like(target_h, 0.5), max_height=0.5)
     shape.heightfield.requires_grad_(True)
-    opt = torch.optim.Adam([shape.heightfield], lr=lr)                                    # optimizers.py:204-300
+    opt = hf_amd.Adam(shape, lr=lr)                       # hf_adam_step: optimizers.py:263-300 + params.update
     hist = []
     t0 = time.perf_counter()
     for it in range(steps):
-        opt.zero_grad(set_to_none=True)
+        opt.zero_grad()
         shade, depth, valid = render(shape, ray, lights)
         both = valid & tgt_valid
         loss = (((shade - tgt_shade) ** 2).sum(0) * both).sum() / both.sum() \
             + 10.0 * (((depth - tgt_depth) ** 2) * both).sum() / both.sum()
         loss.backward()
         hf_amd.allreduce_gradient(shape.heightfield.grad)
-        opt.step()
-        shape.parameters_changed(["heightfield"])                                         # rebuild the mips
+        opt.step()                                            # Adam update + rebuild of the acceleration data
         hist.append(float(loss.detach()))
         if it == 0:  # the first step pays the one-off costs (code-object load, allocator warm-up)
             torch.cuda.synchronize()

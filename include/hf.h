@@ -152,6 +152,19 @@ int hf_destroy(hf_field_t *hf);
 int hf_set_heights(hf_field_t *hf, const float *d_heights, hf_stream_t stream);
 /* same from HOST memory (synchronous copy) */
 int hf_set_heights_host(hf_field_t *hf, const float *h_heights, hf_stream_t stream);
+/* Replaces: mitsuba.ad.Adam.step() for this parameter (src/python/python/ad/optimizers.py:263-300) followed
+ * by params.update() -> parameters_changed({"heightfield"}) (src/python/python/util.py:185-232): one
+ * Adam step on the caller's parameter buffer d_heights[width*height] (DEVICE, updated in place) with the
+ * gradient d_grad and the moment buffers d_m, d_v (zero them before step 1; `step` counts from 1), then
+ * hf_set_heights(hf, d_heights).  lr_t = lr * sqrt(1 - beta2^step) / (1 - beta1^step);
+ * m = beta1 m + (1-beta1) g;  v = beta2 v + (1-beta2) g^2;  h -= lr_t m / (sqrt(v) + eps);
+ * mask_updates != 0 leaves h, m, v untouched where g == 0 (optimizers.py:282-285, 293-294).
+ * The hyper-parameters are host doubles like the reference's Python scalars: the bias-correction scale is
+ * evaluated in double and rounded once (optimizers.py:267-268), everything else runs in float32.
+ * The 'uniform' variant (max of v) is not provided. */
+int hf_adam_step(hf_field_t *hf, float *d_heights, const float *d_grad, float *d_m, float *d_v, double lr,
+                 double beta1, double beta2, double eps, uint32_t step, int mask_updates, hf_stream_t stream);
+
 /* Replaces: m_to_world update + update() (rectangle.cpp:101-112, 131-142). */
 int hf_set_transform(hf_field_t *hf, const float to_world[12], const float *to_object_or_null);
 

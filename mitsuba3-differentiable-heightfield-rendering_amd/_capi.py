@@ -41,6 +41,8 @@ SYMBOLS = {
     "hf_destroy": (C.c_int, [C.c_void_p]),
     "hf_set_heights": (C.c_int, [C.c_void_p, _fp, C.c_void_p]),
     "hf_set_heights_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hf_adam_step": (C.c_int, [C.c_void_p, _fp, _fp, _fp, _fp, C.c_double, C.c_double, C.c_double, C.c_double,
+                               C.c_uint32, C.c_int, C.c_void_p]),
     "hf_set_transform": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "hf_bbox": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "hf_heights_device": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),

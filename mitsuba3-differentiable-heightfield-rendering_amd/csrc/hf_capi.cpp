@@ -174,6 +174,23 @@ extern "C" int hf_set_heights(hf_field_t *hf, const float *d_heights, hf_stream_
     return HF_OK;
 }
 
+extern "C" int hf_adam_step(hf_field_t *hf, float *d_heights, const float *d_grad, float *d_m, float *d_v, double lr,
+                            double beta1, double beta2, double eps, uint32_t step, int mask_updates,
+                            hf_stream_t stream) {
+    if (!hf || !d_heights || !d_grad || !d_m || !d_v) return fail(HF_EINVAL, "hf_adam_step: NULL argument");
+    // optimizers.py:248-249
+    if (!(beta1 >= 0. && beta1 < 1.) || !(beta2 >= 0. && beta2 < 1.) || !(lr > 0.) || !(eps > 0.) || step == 0)
+        return fail(HF_EINVAL, "hf_adam_step: need 0 <= beta < 1, lr > 0, eps > 0, step >= 1");
+    HF_HIP(hipSetDevice(hf->device));
+    // lr_scale in double, rounded once, like the Python scalar the reference makes opaque (optimizers.py:267-268)
+    const float lr_scale = (float) (sqrt(1.0 - pow(beta2, (double) step)) / (1.0 - pow(beta1, (double) step)));
+    const float lr_t = (float) lr * lr_scale;
+    hf_launch_adam((size_t) hf->dev.W * hf->dev.H, d_heights, d_grad, d_m, d_v, lr_t, (float) beta1, (float) beta2,
+                   (float) eps, mask_updates, (hipStream_t) stream);
+    HF_HIP(hipGetLastError());
+    return hf_set_heights(hf, d_heights, stream);
+}
+
 extern "C" int hf_set_heights_host(hf_field_t *hf, const float *h_heights, hf_stream_t stream) {
     if (!hf || !h_heights) return fail(HF_EINVAL, "hf_set_heights_host: NULL argument");
     hipStream_t st = (hipStream_t) stream;

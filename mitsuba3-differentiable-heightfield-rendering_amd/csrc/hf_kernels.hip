@@ -1044,3 +1044,28 @@ void hf_launch_adjoint(const hf_dev_field &f, size_t n, const hf_rays_t *rays, c
                        grad_o ? grad_o[2] : nullptr, grad_d ? grad_d[0] : nullptr, grad_d ? grad_d[1] : nullptr,
                        grad_d ? grad_d[2] : nullptr);
 }
+
+// ---------------------------------------------------------------------------------
+// Adam step on the height texture (optimizers.py:263-300), explicit operation order (no contraction)
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(HF_BLOCK) void hf_adam_kernel(size_t n, float *__restrict__ h, const float *__restrict__ g,
+                                                          float *__restrict__ m, float *__restrict__ v, float lr_t,
+                                                          float beta1, float beta2, float eps, int mask_updates) {
+    const size_t stride = (size_t) gridDim.x * HF_BLOCK;
+    const float c1 = 1.f - beta1, c2 = 1.f - beta2;
+    for (size_t i = (size_t) blockIdx.x * HF_BLOCK + threadIdx.x; i < n; i += stride) {
+        const float gi = g[i];
+        if (mask_updates && gi == 0.f) continue;
+        const float mt = beta1 * m[i] + c1 * gi;
+        const float vt = beta2 * v[i] + c2 * (gi * gi);
+        m[i] = mt; v[i] = vt;
+        h[i] = h[i] - (lr_t * mt) / (__builtin_sqrtf(vt) + eps);
+    }
+}
+
+void hf_launch_adam(size_t n, float *h, const float *g, float *m, float *v, float lr_t, float beta1, float beta2,
+                    float eps, int mask_updates, hipStream_t stream) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(hf_adam_kernel, dim3(grid_for(n)), dim3(HF_BLOCK), 0, stream, n, h, g, m, v, lr_t, beta1, beta2,
+                       eps, mask_updates);
+}

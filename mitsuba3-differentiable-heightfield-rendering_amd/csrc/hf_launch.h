@@ -15,3 +15,5 @@ void hf_launch_si(const hf_dev_field &f, size_t n, const hf_rays_t *rays, const 
 void hf_launch_adjoint(const hf_dev_field &f, size_t n, const hf_rays_t *rays, const hf_pi_const_t *pi,
                        const uint8_t *active, const hf_si_grad_t *gs, uint32_t flags, float *grad_h,
                        float *const grad_o[3], float *const grad_d[3], hipStream_t stream);
+void hf_launch_adam(size_t n, float *h, const float *g, float *m, float *v, float lr_t, float beta1, float beta2,
+                    float eps, int mask_updates, hipStream_t stream);

@@ -479,3 +479,47 @@ def allreduce_gradient(grad, group=None):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(grad, op=dist.ReduceOp.SUM, group=group)
     return grad
+
+
+class Adam:
+    """Adam on the heightfield parameter of one shape, the mirror of ``mitsuba.ad.Adam``
+    (src/python/python/ad/optimizers.py:204-310) + ``params.update()`` (util.py:185-232):
+    ``step()`` runs ``hf_adam_step`` -- the update of the parameter tensor in place and the rebuild
+    of the shape's acceleration data -- in one call on the current stream.  State (m, v, t) lives here,
+    like ``Optimizer.state`` / ``Adam.t``.  The 'uniform' variant is not provided."""
+
+    def __init__(self, shape, lr, beta_1=0.9, beta_2=0.999, epsilon=1e-8, mask_updates=False):
+        assert 0 <= beta_1 < 1 and 0 <= beta_2 < 1 and lr > 0 and epsilon > 0  # optimizers.py:248-249
+        self.shape, self.lr, self.beta_1, self.beta_2, self.epsilon = shape, lr, beta_1, beta_2, epsilon
+        self.mask_updates = mask_updates
+        self.reset()
+
+    def reset(self):
+        """zero-initialise the optimiser state (optimizers.py:303-309)"""
+        h = self.shape.heightfield
+        self.state = (torch.zeros_like(h, requires_grad=False), torch.zeros_like(h, requires_grad=False))
+        self.t = 0
+
+    def set_learning_rate(self, lr):
+        self.lr = lr
+
+    def zero_grad(self):
+        self.shape.heightfield.grad = None
+
+    def step(self):
+        h = self.shape.heightfield
+        g = h.grad
+        if g is None:  # optimizers.py:274-275: nothing to do without a gradient
+            return
+        if not (h.is_cuda and h.dtype == torch.float32 and h.is_contiguous()):
+            raise RuntimeError("Adam: the heightfield parameter must be a contiguous float32 device tensor")
+        g = g.to(dtype=torch.float32).contiguous()
+        self.t += 1
+        m, v = self.state
+        stream = torch.cuda.current_stream(h.device).cuda_stream
+        check(_capi.lib().hf_adam_step(self.shape._h, h.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(),
+                                       self.lr, self.beta_1, self.beta_2, self.epsilon, self.t,
+                                       1 if self.mask_updates else 0, stream))
+        self.shape._heights_keepalive = h
+        self.shape._heights_version += 1
+        self.shape.mark_dirty()

@@ -228,3 +228,25 @@ def sample_tea_32(v0, v1, rounds=4):
     out = (C.c_uint32 * 2)()
     lib().hfo_sample_tea_32(v0, v1, rounds, out)
     return int(out[0]), int(out[1])
+
+
+def adam_step(h, g, m, v, lr, beta1=0.9, beta2=0.999, eps=1e-8, step=1, mask_updates=False):
+    """One Adam step on the height texture, restating mitsuba.ad.Adam.step
+    (src/python/python/ad/optimizers.py:263-300) in float32 with one rounding per operation:
+    lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t)   (scale in double, rounded once, :267-268)
+    m = beta1 m + (1 - beta1) g;  v = beta2 v + (1 - beta2) g^2   (:279-281)
+    h = h - lr_t m / (sqrt(v) + eps)                               (:290-295)
+    mask_updates: entries with g == 0 keep h, m, v (:282-285, 293-294).  Returns (h, m, v) as new arrays."""
+    f = np.float32
+    h, g, m, v = (np.asarray(a, f) for a in (h, g, m, v))
+    lr_scale = f(np.sqrt(1.0 - float(beta2) ** int(step)) / (1.0 - float(beta1) ** int(step)))
+    lr_t = f(f(lr) * lr_scale)
+    b1, b2, e = f(beta1), f(beta2), f(eps)
+    c1, c2 = f(f(1) - b1), f(f(1) - b2)
+    mt = (b1 * m + c1 * g).astype(f)
+    vt = (b2 * v + c2 * (g * g).astype(f)).astype(f)
+    hn = (h - ((lr_t * mt).astype(f) / (np.sqrt(vt).astype(f) + e).astype(f)).astype(f)).astype(f)
+    if mask_updates:
+        z = g == 0
+        mt = np.where(z, m, mt); vt = np.where(z, v, vt); hn = np.where(z, h, hn)
+    return hn, mt, vt
