@@ -186,6 +186,10 @@ def main():
     return out
 
 
+def _rows_of(buf, n):
+    return [buf.data_ptr() + 4 * n * k for k in range(buf.shape[0])]
+
+
 def other_launches(torch, hf_amd, _capi, lib, shape, r_s, pi_s, si_s, si, R, stream, flags, iters=3):
     """Not part of `value`: the other entry points of the path on the same wavefront, and on the incoherent
     secondary rays of SURVEY 8d (one cosine bounce + one shadow ray per primary hit), HIP-event ms per launch."""
@@ -204,6 +208,31 @@ def other_launches(torch, hf_amd, _capi, lib, shape, r_s, pi_s, si_s, si, R, str
     }
     out = {}
     for name, f in fn.items():
+        _capi.check(f()); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            _capi.check(f())
+        e1.record(); torch.cuda.synchronize()
+        out[name] = round(e0.elapsed_time(e1) / iters, 4)
+    # next-row kernels: direct lighting of the wavefront under 4 directional lights, and its adjoint
+    K = 4
+    L = (_capi.hf_dir_light_t * K)()
+    for k, (x, y, z) in enumerate([(0.5, 0.2, 0.84), (-0.5, 0.3, 0.81), (0.1, -0.6, 0.79), (0.0, 0.0, 1.0)]):
+        nrm = math.sqrt(x * x + y * y + z * z)
+        L[k].to_light[0], L[k].to_light[1], L[k].to_light[2], L[k].irradiance = x / nrm, y / nrm, z / nrm, math.pi
+    spp = 64 if R % 64 == 0 else 1
+    img = torch.empty((K, R // spp), dtype=torch.float32, device=dev)
+    gimg = torch.ones_like(img)
+    gn = torch.empty((3, R), dtype=torch.float32, device=dev)
+    rows = _rows_of(si, R)
+    shn = (C.c_void_p * 3)(*rows[9:12]); gnp = (C.c_void_p * 3)(*_rows_of(gn, R))
+    dd = (C.c_void_p * 3)(r_s.d[0], r_s.d[1], r_s.d[2])
+    more = {
+        "direct_lighting(4 lights)": lambda: lib.hf_direct_lighting(R, spp, C.byref(shn), C.byref(dd), rows[0], K, L, 1.0, None, img.data_ptr(), stream),
+        "direct_lighting_adjoint": lambda: lib.hf_direct_lighting_adjoint(R, spp, C.byref(shn), C.byref(dd), rows[0], K, L, 1.0, None, gimg.data_ptr(), C.byref(gnp), stream),
+    }
+    for name, f in more.items():
         _capi.check(f()); torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

@@ -4,8 +4,8 @@ from multi-light renders"; the notebook in the reference snapshot contains no su
 
 A minimal direct-lighting differentiable render on top of the heightfield shape:
     primary rays (orthographic)  ->  shape.ray_intersect (HIP traversal + fused SI)
-    image_k = albedo * max(0, <n, l_k>)  for K directional lights,  depth = t
-    loss = sum_k |image_k - target_k|^2 + lambda |depth - depth_target|^2     (valid pixels)
+    image_k = box-filtered  albedo/pi * E * max(0, <n, l_k>)  for K directional lights (hf_direct_lighting),  depth = t
+    loss = sum_k |image_k - target_k|^2 + lambda |depth - depth_target|^2
     loss.backward()  ->  HIP adjoint scatters dL/dheight;  hf_amd.Adam.step() = hf_adam_step: Adam update on the
         device + rebuild of the acceleration data (what params.update / scene.parameters_changed do once per
         optimiser step, util.py:185-232, scene.cpp:343-385)
@@ -16,6 +16,7 @@ With torch.distributed initialised (torchrun), every rank renders its own spp se
 texture is summed with one all-reduce per step.
 """
 import argparse
+import math
 import os
 import sys
 import time
@@ -28,17 +29,18 @@ import hf_amd  # noqa: E402
 LIGHTS = torch.tensor([[0.5, 0.2, 0.84], [-0.5, 0.3, 0.81], [0.1, -0.6, 0.79], [0.0, 0.0, 1.0]])
 
 
-def render(shape, ray, lights):
+def render(shape, ray, lights, spp):
     si = shape.ray_intersect(ray, hf_amd.RayFlags.All)
     valid = si.is_valid()
-    shade = torch.clamp(torch.einsum("kc,cn->kn", lights, si.n), min=0.0) * valid       # [K, n]
+    # diffuse direct lighting + box-filter film on the wavefront (hf_direct_lighting): [K, pixels]
+    images = hf_amd.direct_lighting(si, ray, lights, albedo=1.0, spp=spp)
     depth = torch.where(valid, si.t, torch.zeros_like(si.t))
-    return shade, depth, valid
+    return images, depth, valid
 
 
 def run(grid=128, film=256, spp=1, steps=100, lr=0.02, device="cuda", verbose=True, seed=0):
     dev = torch.device(device)
-    lights = (LIGHTS / LIGHTS.norm(dim=1, keepdim=True)).to(dev)
+    lights = torch.cat([LIGHTS / LIGHTS.norm(dim=1, keepdim=True), torch.full((len(LIGHTS), 1), math.pi)], 1)  # E = pi
     target_h = hf_amd.workload.sine_heights(grid, grid, device=dev)
     # camera looking down at 30 degrees off vertical so that every ray meets the surface
     rays = hf_amd.workload.ortho_rays(film, film, spp, dev, seed=seed, origin=(0.6, 0.35, 2.0),
@@ -46,7 +48,7 @@ def run(grid=128, film=256, spp=1, steps=100, lr=0.02, device="cuda", verbose=Tr
     ray = hf_amd.Ray3f(rays[0:3], rays[3:6], rays[6])
     target = hf_amd.Heightfield(heightfield=target_h, max_height=0.5)
     with torch.no_grad():
-        tgt_shade, tgt_depth, tgt_valid = render(target, ray, lights)
+        tgt_img, tgt_depth, tgt_valid = render(target, ray, lights, spp)
     shape = hf_amd.Heightfield(heightfield=torch.full_like(target_h, 0.5), max_height=0.5)
     shape.heightfield.requires_grad_(True)
     opt = hf_amd.Adam(shape, lr=lr)                       # hf_adam_step: optimizers.py:263-300 + params.update
@@ -54,9 +56,9 @@ def run(grid=128, film=256, spp=1, steps=100, lr=0.02, device="cuda", verbose=Tr
     t0 = time.perf_counter()
     for it in range(steps):
         opt.zero_grad()
-        shade, depth, valid = render(shape, ray, lights)
+        images, depth, valid = render(shape, ray, lights, spp)
         both = valid & tgt_valid
-        loss = (((shade - tgt_shade) ** 2).sum(0) * both).sum() / both.sum() \
+        loss = ((images - tgt_img) ** 2).sum(0).mean() \
             + 10.0 * (((depth - tgt_depth) ** 2) * both).sum() / both.sum()
         loss.backward()
         hf_amd.allreduce_gradient(shape.heightfield.grad)

@@ -216,6 +216,38 @@ int hf_adjoint(const hf_field_t *hf, size_t n, const hf_rays_t *rays,
                const hf_si_grad_t *grad_si, float *grad_heights,
                float *const grad_o[3], float *const grad_d[3], hf_stream_t stream);
 
+/* ---- next row: minimal direct lighting on the wavefront ------- */
+
+/* A directional emitter (src/emitters/directional.cpp:82,174): unit direction TOWARDS the light, scalar irradiance. */
+#define HF_MAX_LIGHTS 8
+typedef struct hf_dir_light {
+    float to_light[3];
+    float irradiance;
+} hf_dir_light_t;
+
+/* Replaces, for diffuse surfaces under directional lights, the emitter-sampling term of the direct
+ * integrator (src/python/python/ad/integrators/direct_reparam.py:149-175: detached emitter sample, delta
+ * light => MIS weight 1, attached BSDF value) with the diffuse BSDF (src/bsdfs/diffuse.cpp:135-140:
+ * albedo/pi * cos_o, zero unless cos_i > 0 and cos_o > 0 in the shading frame) and the box-filter film
+ * (mean of the spp samples of a pixel, sample i belongs to pixel i / spp as in
+ * src/render/integrator.cpp:251-268):
+ *   image[k][i / spp] = 1/spp * sum_s  albedo/pi * E_k * max(0, <sh_n, l_k>) * vis_k      (t finite, <sh_n,-d> > 0)
+ * sh_n, d: 3 device arrays of n floats each (SoA, as hf_si_t.sh_n / hf_rays_t.d); t: n floats (inf = miss);
+ * lights: n_lights <= HF_MAX_LIGHTS structs in HOST memory; vis: NULL or n_lights device arrays of n bytes
+ * (0 = shadowed: the negated hf_ray_test result of the shadow ray towards light k); image: device,
+ * n_lights * (n / spp) floats, overwritten.  n must be a multiple of spp. */
+int hf_direct_lighting(size_t n, uint32_t spp, const float *const sh_n[3], const float *const d[3], const float *t,
+                       uint32_t n_lights, const hf_dir_light_t *lights, float albedo, const uint8_t *const *vis,
+                       float *image, hf_stream_t stream);
+/* Reverse mode of the above with respect to sh_n (what dr.backward propagates into si before it reaches
+ * compute_surface_interaction; the cos > 0 masks and the visibility are piecewise constant):
+ *   grad_sh_n[i] = 1/spp * sum_k  albedo/pi * E_k * vis_k * grad_image[k][i / spp] * l_k      (same masks)
+ * grad_sh_n: 3 device arrays of n floats, overwritten; feed them to hf_adjoint as hf_si_grad_t.sh_n. */
+int hf_direct_lighting_adjoint(size_t n, uint32_t spp, const float *const sh_n[3], const float *const d[3],
+                               const float *t, uint32_t n_lights, const hf_dir_light_t *lights, float albedo,
+                               const uint8_t *const *vis, const float *grad_image, float *const grad_sh_n[3],
+                               hf_stream_t stream);
+
 /* ---- introspection (tests / tools) --------------------------------------------- */
 int hf_num_levels(const hf_field_t *hf);
 /* copies mip level `level` (1..num_levels) to HOST memory as (min,max) pairs,

@@ -36,6 +36,13 @@ class hf_si_grad_t(C.Structure):
 
 
 # every symbol include/hf.h declares: name -> (restype, argtypes)
+HF_MAX_LIGHTS = 8
+
+
+class hf_dir_light_t(C.Structure):
+    _fields_ = [("to_light", C.c_float * 3), ("irradiance", C.c_float)]
+
+
 SYMBOLS = {
     "hf_create": (C.c_int, [C.POINTER(hf_desc_t), C.POINTER(C.c_void_p)]),
     "hf_destroy": (C.c_int, [C.c_void_p]),
@@ -58,6 +65,11 @@ SYMBOLS = {
     "hf_adjoint": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(hf_rays_t), C.POINTER(hf_pi_t),
                              C.c_uint32, _fp, C.POINTER(hf_si_grad_t), _fp,
                              C.POINTER(_fp * 3), C.POINTER(_fp * 3), C.c_void_p]),
+    "hf_direct_lighting": (C.c_int, [C.c_size_t, C.c_uint32, C.POINTER(_fp * 3), C.POINTER(_fp * 3), _fp, C.c_uint32,
+                                     C.POINTER(hf_dir_light_t), C.c_float, C.POINTER(_fp), _fp, C.c_void_p]),
+    "hf_direct_lighting_adjoint": (C.c_int, [C.c_size_t, C.c_uint32, C.POINTER(_fp * 3), C.POINTER(_fp * 3), _fp,
+                                             C.c_uint32, C.POINTER(hf_dir_light_t), C.c_float, C.POINTER(_fp), _fp,
+                                             C.POINTER(_fp * 3), C.c_void_p]),
     "hf_num_levels": (C.c_int, [C.c_void_p]),
     "hf_get_mip": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_uint32),
                              C.POINTER(C.c_uint32)]),

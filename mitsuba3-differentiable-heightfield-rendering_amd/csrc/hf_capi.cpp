@@ -349,3 +349,50 @@ extern "C" int hf_adjoint(const hf_field_t *hf, size_t n, const hf_rays_t *rays,
     HF_HIP(hipGetLastError());
     return HF_OK;
 }
+
+// ---- minimal direct lighting --------------------------------------------------
+static int pack_lights(const char *who, size_t n, uint32_t spp, const float *const sh_n[3], const float *const d[3],
+                       const float *t, uint32_t n_lights, const hf_dir_light_t *lights, float albedo,
+                       const uint8_t *const *vis, hf_lights_dev &L) {
+    if (!sh_n || !d || !t || !lights) return fail(HF_EINVAL, "%s: NULL argument", who);
+    for (int k = 0; k < 3; ++k)
+        if (!sh_n[k] || !d[k]) return fail(HF_EINVAL, "%s: NULL component array", who);
+    if (spp == 0 || n % spp != 0) return fail(HF_EINVAL, "%s: n (%zu) must be a multiple of spp (%u)", who, n, spp);
+    if (n_lights == 0 || n_lights > HF_MAX_LIGHTS)
+        return fail(HF_EINVAL, "%s: 1..%d lights supported (got %u)", who, HF_MAX_LIGHTS, n_lights);
+    if ((size_t) (n / spp) * n_lights >= ((size_t) 1 << 32)) return fail(HF_EINVAL, "%s: image too large", who);
+    L.n = n_lights;
+    for (uint32_t k = 0; k < HF_MAX_LIGHTS; ++k) {
+        const bool on = k < n_lights;
+        for (int c = 0; c < 3; ++c) L.l[k][c] = on ? lights[k].to_light[c] : 0.f;
+        L.w[k] = on ? (albedo * 0.31830988618379067154f) * lights[k].irradiance : 0.f; // dr::InvPi
+        L.vis[k] = (on && vis) ? vis[k] : nullptr;
+    }
+    return HF_OK;
+}
+
+extern "C" int hf_direct_lighting(size_t n, uint32_t spp, const float *const sh_n[3], const float *const d[3],
+                                  const float *t, uint32_t n_lights, const hf_dir_light_t *lights, float albedo,
+                                  const uint8_t *const *vis, float *image, hf_stream_t stream) {
+    hf_lights_dev L;
+    const int rc = pack_lights("hf_direct_lighting", n, spp, sh_n, d, t, n_lights, lights, albedo, vis, L);
+    if (rc != HF_OK) return rc;
+    if (!image) return fail(HF_EINVAL, "hf_direct_lighting: NULL image");
+    hf_launch_direct(n, spp, sh_n, d, t, L, image, (hipStream_t) stream);
+    HF_HIP(hipGetLastError());
+    return HF_OK;
+}
+
+extern "C" int hf_direct_lighting_adjoint(size_t n, uint32_t spp, const float *const sh_n[3], const float *const d[3],
+                                          const float *t, uint32_t n_lights, const hf_dir_light_t *lights,
+                                          float albedo, const uint8_t *const *vis, const float *grad_image,
+                                          float *const grad_sh_n[3], hf_stream_t stream) {
+    hf_lights_dev L;
+    const int rc = pack_lights("hf_direct_lighting_adjoint", n, spp, sh_n, d, t, n_lights, lights, albedo, vis, L);
+    if (rc != HF_OK) return rc;
+    if (!grad_image || !grad_sh_n || !grad_sh_n[0] || !grad_sh_n[1] || !grad_sh_n[2])
+        return fail(HF_EINVAL, "hf_direct_lighting_adjoint: NULL gradient array");
+    hf_launch_direct_adjoint(n, spp, sh_n, d, t, L, grad_image, grad_sh_n, (hipStream_t) stream);
+    HF_HIP(hipGetLastError());
+    return HF_OK;
+}

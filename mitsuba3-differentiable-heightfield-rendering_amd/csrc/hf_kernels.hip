@@ -1069,3 +1069,80 @@ void hf_launch_adam(size_t n, float *h, const float *g, float *m, float *v, floa
     hipLaunchKernelGGL(hf_adam_kernel, dim3(grid_for(n)), dim3(HF_BLOCK), 0, stream, n, h, g, m, v, lr_t, beta1, beta2,
                        eps, mask_updates);
 }
+
+// ---------------------------------------------------------------------------------
+// Minimal direct lighting on the wavefront (include/hf.h): one lane per sample, coalesced SoA loads,
+// the box-filter film as a shuffle tree over the samples of a pixel.  Pure streaming: 28 B/sample in.
+// ---------------------------------------------------------------------------------
+struct hf_f3ptr { const float *p[3]; };
+struct hf_f3out { float *p[3]; };
+
+__global__ __launch_bounds__(HF_BLOCK) void hf_direct_kernel(size_t n, uint32_t spp, hf_f3ptr sn, hf_f3ptr dd,
+                                                            const float *__restrict__ t, hf_lights_dev L,
+                                                            float *__restrict__ image) {
+    const size_t i = (size_t) blockIdx.x * HF_BLOCK + threadIdx.x;
+    const size_t npix = n / spp;
+    const bool in = i < n;
+    const size_t ii = in ? i : n - 1;
+    const v3 nn = mk3(sn.p[0][ii], sn.p[1][ii], sn.p[2][ii]);
+    const v3 d = mk3(dd.p[0][ii], dd.p[1][ii], dd.p[2][ii]);
+    const bool lit = in && (t[ii] != __builtin_inff()) && (-dot3(nn, d) > 0.f); // hit, seen from the front (diffuse.cpp:137)
+    const bool pow2 = (spp & (spp - 1u)) == 0u;
+    const uint32_t g = spp < 64u ? spp : 64u; // lanes per pixel within a wave (tree path)
+    const float inv_spp = 1.0f / (float) spp;
+    for (uint32_t k = 0; k < L.n; ++k) {
+        const float co = dot3(nn, mk3(L.l[k][0], L.l[k][1], L.l[k][2]));
+        float c = (lit && co > 0.f && (L.vis[k] ? L.vis[k][ii] != 0 : true)) ? L.w[k] * co : 0.f;
+        if (pow2) {
+            for (uint32_t off = 1; off < g; off <<= 1) c += __shfl_xor(c, (int) off);
+            if (in && (threadIdx.x & (g - 1u)) == 0u) {
+                if (spp <= 64u) image[k * npix + i / spp] = c * inv_spp;          // the wave holds whole pixels
+                else            atomicAdd(&image[k * npix + i / spp], c * inv_spp); // several waves per pixel
+            }
+        } else if (in) {
+            atomicAdd(&image[k * npix + i / spp], c * inv_spp);
+        }
+    }
+}
+
+__global__ __launch_bounds__(HF_BLOCK) void hf_direct_adjoint_kernel(size_t n, uint32_t spp, hf_f3ptr sn, hf_f3ptr dd,
+                                                                    const float *__restrict__ t, hf_lights_dev L,
+                                                                    const float *__restrict__ gimg, hf_f3out gn) {
+    const size_t i = (size_t) blockIdx.x * HF_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const size_t npix = n / spp, pix = i / spp;
+    const v3 nn = mk3(sn.p[0][i], sn.p[1][i], sn.p[2][i]);
+    const v3 d = mk3(dd.p[0][i], dd.p[1][i], dd.p[2][i]);
+    const bool lit = (t[i] != __builtin_inff()) && (-dot3(nn, d) > 0.f);
+    const float inv_spp = 1.0f / (float) spp;
+    v3 g = mk3(0.f, 0.f, 0.f);
+    for (uint32_t k = 0; k < L.n; ++k) {
+        const v3 l = mk3(L.l[k][0], L.l[k][1], L.l[k][2]);
+        if (lit && dot3(nn, l) > 0.f && (L.vis[k] ? L.vis[k][i] != 0 : true)) {
+            const float w = (L.w[k] * inv_spp) * gimg[k * npix + pix];
+            g.x = __builtin_fmaf(w, l.x, g.x); g.y = __builtin_fmaf(w, l.y, g.y); g.z = __builtin_fmaf(w, l.z, g.z);
+        }
+    }
+    gn.p[0][i] = g.x; gn.p[1][i] = g.y; gn.p[2][i] = g.z;
+}
+
+void hf_launch_direct(size_t n, uint32_t spp, const float *const sh_n[3], const float *const d[3], const float *t,
+                      const hf_lights_dev &lights, float *image, hipStream_t stream) {
+    if (n == 0) return;
+    const bool pow2 = (spp & (spp - 1u)) == 0u;
+    if (!pow2 || spp > 64u) (void) hipMemsetAsync(image, 0, sizeof(float) * lights.n * (n / spp), stream); // atomic paths
+    hf_f3ptr sn = { { sh_n[0], sh_n[1], sh_n[2] } }, dd = { { d[0], d[1], d[2] } };
+    const size_t blocks = (n + HF_BLOCK - 1) / HF_BLOCK;
+    hipLaunchKernelGGL(hf_direct_kernel, dim3((unsigned) blocks), dim3(HF_BLOCK), 0, stream, n, spp, sn, dd, t, lights, image);
+}
+
+void hf_launch_direct_adjoint(size_t n, uint32_t spp, const float *const sh_n[3], const float *const d[3],
+                              const float *t, const hf_lights_dev &lights, const float *grad_image,
+                              float *const grad_sh_n[3], hipStream_t stream) {
+    if (n == 0) return;
+    hf_f3ptr sn = { { sh_n[0], sh_n[1], sh_n[2] } }, dd = { { d[0], d[1], d[2] } };
+    hf_f3out gn = { { grad_sh_n[0], grad_sh_n[1], grad_sh_n[2] } };
+    const size_t blocks = (n + HF_BLOCK - 1) / HF_BLOCK;
+    hipLaunchKernelGGL(hf_direct_adjoint_kernel, dim3((unsigned) blocks), dim3(HF_BLOCK), 0, stream, n, spp, sn, dd, t,
+                       lights, grad_image, gn);
+}

@@ -17,3 +17,14 @@ void hf_launch_adjoint(const hf_dev_field &f, size_t n, const hf_rays_t *rays, c
                        float *const grad_o[3], float *const grad_d[3], hipStream_t stream);
 void hf_launch_adam(size_t n, float *h, const float *g, float *m, float *v, float lr_t, float beta1, float beta2,
                     float eps, int mask_updates, hipStream_t stream);
+struct hf_lights_dev {
+    float l[HF_MAX_LIGHTS][3];
+    float w[HF_MAX_LIGHTS]; // albedo/pi * irradiance
+    const uint8_t *vis[HF_MAX_LIGHTS];
+    uint32_t n;
+};
+void hf_launch_direct(size_t n, uint32_t spp, const float *const sh_n[3], const float *const d[3], const float *t,
+                      const hf_lights_dev &lights, float *image, hipStream_t stream);
+void hf_launch_direct_adjoint(size_t n, uint32_t spp, const float *const sh_n[3], const float *const d[3],
+                              const float *t, const hf_lights_dev &lights, const float *grad_image,
+                              float *const grad_sh_n[3], hipStream_t stream);

@@ -523,3 +523,60 @@ class Adam:
         self.shape._heights_keepalive = h
         self.shape._heights_version += 1
         self.shape.mark_dirty()
+
+
+def _f3(x):
+    """[3, n] float32 device tensor -> (keepalive, ctypes array of 3 row pointers)"""
+    x = x.to(dtype=torch.float32).contiguous()
+    return x, (C.c_void_p * 3)(x[0].data_ptr(), x[1].data_ptr(), x[2].data_ptr())
+
+
+class _DirectLightingOp(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, sh_n, d, t, lights, albedo, spp, vis):
+        n = sh_n.shape[1]
+        K = lights.shape[0]
+        sn, sn_p = _f3(sh_n)
+        dd, dd_p = _f3(d)
+        tt = t.to(dtype=torch.float32).contiguous()
+        L = (_capi.hf_dir_light_t * K)()
+        lh = lights.detach().cpu().tolist()
+        for k in range(K):
+            L[k].to_light[0], L[k].to_light[1], L[k].to_light[2], L[k].irradiance = lh[k]
+        vis_p = None
+        if vis is not None:
+            vis = vis.to(dtype=torch.uint8).contiguous()
+            vis_p = (C.c_void_p * K)(*[vis[k].data_ptr() for k in range(K)])
+        image = torch.empty((K, n // spp), dtype=torch.float32, device=sh_n.device)
+        stream = torch.cuda.current_stream(sh_n.device).cuda_stream
+        check(_capi.lib().hf_direct_lighting(n, spp, C.byref(sn_p), C.byref(dd_p), tt.data_ptr(), K, L, albedo,
+                                             vis_p, image.data_ptr(), stream))
+        ctx.save_for_backward(sn, dd, tt)
+        ctx.misc = (L, K, albedo, spp, vis, vis_p)
+        return image
+
+    @staticmethod
+    def backward(ctx, grad_image):
+        sn, dd, tt = ctx.saved_tensors
+        L, K, albedo, spp, vis, vis_p = ctx.misc
+        n = sn.shape[1]
+        _, sn_p = _f3(sn)
+        _, dd_p = _f3(dd)
+        gi = grad_image.to(dtype=torch.float32).contiguous()
+        gn = torch.empty_like(sn)
+        gn_p = (C.c_void_p * 3)(gn[0].data_ptr(), gn[1].data_ptr(), gn[2].data_ptr())
+        stream = torch.cuda.current_stream(sn.device).cuda_stream
+        check(_capi.lib().hf_direct_lighting_adjoint(n, spp, C.byref(sn_p), C.byref(dd_p), tt.data_ptr(), K, L, albedo,
+                                                     vis_p, gi.data_ptr(), C.byref(gn_p), stream))
+        return gn, None, None, None, None, None, None
+
+
+def direct_lighting(si, ray, lights, albedo=1.0, spp=1, vis=None):
+    """Diffuse direct lighting under directional lights + box-filter film, on the wavefront
+    (``hf_direct_lighting``; the emitter-sampling term of direct_reparam.py:149-175 with diffuse.cpp:135-140).
+    ``lights``: [K, 4] tensor of (unit direction towards the light, irradiance); ``vis``: optional [K, n] uint8,
+    0 = shadowed (``~shape.ray_test(shadow ray)``).  Returns the [K, n // spp] images; differentiable with
+    respect to ``si.sh_frame.n`` (``hf_direct_lighting_adjoint``), which carries the gradient on to
+    ``hf_adjoint`` and the heights."""
+    lights = torch.as_tensor(lights, dtype=torch.float32)
+    return _DirectLightingOp.apply(si.sh_frame.n, ray.d, si.t, lights, float(albedo), int(spp), vis)

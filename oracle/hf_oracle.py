@@ -250,3 +250,39 @@ def adam_step(h, g, m, v, lr, beta1=0.9, beta2=0.999, eps=1e-8, step=1, mask_upd
         z = g == 0
         mt = np.where(z, m, mt); vt = np.where(z, v, vt); hn = np.where(z, h, hn)
     return hn, mt, vt
+
+
+def direct_lighting(sh_n, d, t, lights, albedo=1.0, spp=1, vis=None):
+    """Diffuse direct lighting under directional lights + box-filter film (float64 restatement of
+    include/hf.h hf_direct_lighting): emitter-sampling term of direct_reparam.py:149-175 for a delta light
+    (MIS weight 1), diffuse BSDF value albedo/pi * cos_o gated by cos_i > 0 and cos_o > 0
+    (src/bsdfs/diffuse.cpp:135-140), irradiance of src/emitters/directional.cpp:174, pixel = sample // spp
+    (src/render/integrator.cpp:251-268).  lights: [K,4] = (unit direction to the light, irradiance).
+    Returns image [K, n // spp]."""
+    sh_n = np.asarray(sh_n, np.float64); d = np.asarray(d, np.float64); t = np.asarray(t, np.float64)
+    lights = np.asarray(lights, np.float64).reshape(-1, 4)
+    n = sh_n.shape[1]
+    lit = np.isfinite(t) & (-(sh_n * d).sum(0) > 0)
+    out = np.zeros((lights.shape[0], n // spp))
+    for k, L in enumerate(lights):
+        co = (sh_n * L[:3, None]).sum(0)
+        c = np.where(lit & (co > 0), albedo / np.pi * L[3] * co, 0.0)
+        if vis is not None:
+            c = c * (np.asarray(vis[k]) != 0)
+        out[k] = c.reshape(-1, spp).mean(1)
+    return out
+
+
+def direct_lighting_adjoint(sh_n, d, t, lights, grad_image, albedo=1.0, spp=1, vis=None):
+    """d(sum(image * grad_image)) / d(sh_n), float64: the cos > 0 masks and the visibility are piecewise constant."""
+    sh_n = np.asarray(sh_n, np.float64); d = np.asarray(d, np.float64); t = np.asarray(t, np.float64)
+    lights = np.asarray(lights, np.float64).reshape(-1, 4)
+    lit = np.isfinite(t) & (-(sh_n * d).sum(0) > 0)
+    g = np.zeros_like(sh_n)
+    for k, L in enumerate(lights):
+        co = (sh_n * L[:3, None]).sum(0)
+        w = np.where(lit & (co > 0), albedo / np.pi * L[3] / spp, 0.0) * np.repeat(np.asarray(grad_image, np.float64)[k], spp)
+        if vis is not None:
+            w = w * (np.asarray(vis[k]) != 0)
+        g += w[None, :] * L[:3, None]
+    return g

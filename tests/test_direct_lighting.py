@@ -1,0 +1,97 @@
+"""Minimal direct lighting on the wavefront: oracle known answers and finite
+differences on CPU; hf_direct_lighting / hf_direct_lighting_adjoint against the oracle on the GPU
+(floating point: 1e-5 relative, the film is a shuffle tree / float atomics), and the end-to-end
+chain lights -> image -> loss -> dL/dheight through autograd."""
+import numpy as np
+import pytest
+
+LIGHTS = np.array([[0.5, 0.2, 0.84, 1.5], [-0.5, 0.3, 0.81, 0.7], [0.0, 0.0, 1.0, 2.0]])
+LIGHTS[:, :3] /= np.linalg.norm(LIGHTS[:, :3], axis=1, keepdims=True)
+
+
+def _samples(n, rng):
+    sh_n = rng.normal(size=(3, n)); sh_n[2] = np.abs(sh_n[2]) + 0.2; sh_n /= np.linalg.norm(sh_n, axis=0)
+    d = rng.normal(size=(3, n)); d[2] = -np.abs(d[2]) - 0.1
+    t = rng.uniform(0.5, 3.0, n); t[rng.uniform(size=n) < 0.2] = np.inf
+    return sh_n.astype(np.float32), d.astype(np.float32), t.astype(np.float32)
+
+
+def test_oracle_known_answers(oracle):
+    n = np.array([[0.0], [0.0], [1.0]]); d = np.array([[0.0], [0.0], [-1.0]]); t = np.array([1.0])
+    img = oracle.direct_lighting(n, d, t, [[0, 0, 1, 2.0]], albedo=0.5)
+    assert np.isclose(img[0, 0], 0.5 / np.pi * 2.0)                       # diffuse.cpp:140 at normal incidence
+    assert oracle.direct_lighting(n, -d, t, [[0, 0, 1, 2.0]])[0, 0] == 0   # seen from the back: cos_i <= 0
+    assert oracle.direct_lighting(n, d, t, [[0, 0, -1, 2.0]])[0, 0] == 0   # lit from below: cos_o <= 0
+    assert oracle.direct_lighting(n, d, np.array([np.inf]), [[0, 0, 1, 2.0]])[0, 0] == 0
+    n4 = np.repeat(n, 4, 1); d4 = np.repeat(d, 4, 1); t4 = np.array([1.0, np.inf, 1.0, np.inf])
+    assert np.isclose(oracle.direct_lighting(n4, d4, t4, [[0, 0, 1, 1.0]], spp=4)[0, 0], 0.5 / np.pi)  # box filter
+
+
+def test_oracle_adjoint_matches_finite_differences(oracle):
+    rng = np.random.default_rng(3)
+    sh_n, d, t = _samples(64, rng)
+    vis = (rng.uniform(size=(3, 64)) < 0.8).astype(np.uint8)
+    gi = rng.normal(size=(3, 16))
+    g = oracle.direct_lighting_adjoint(sh_n, d, t, LIGHTS, gi, albedo=0.7, spp=4, vis=vis)
+    f = lambda x: (oracle.direct_lighting(x, d, t, LIGHTS, albedo=0.7, spp=4, vis=vis) * gi).sum()
+    x = sh_n.astype(np.float64)
+    for (c, i) in [(0, 3), (1, 10), (2, 33), (2, 63)]:
+        e = np.zeros_like(x); e[c, i] = 1e-6
+        assert np.isclose((f(x + e) - f(x - e)) / 2e-6, g[c, i], rtol=1e-6, atol=1e-9)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("spp", [1, 4, 64, 256, 3])
+@pytest.mark.parametrize("with_vis", [False, True])
+def test_gpu_direct_lighting_matches_oracle(hf, oracle, spp, with_vis):
+    import torch
+    rng = np.random.default_rng(spp)
+    n = spp * 1000
+    sh_n, d, t = _samples(n, rng)
+    vis = (rng.uniform(size=(3, n)) < 0.7).astype(np.uint8) if with_vis else None
+    si = hf.SurfaceInteraction3f(); ray = hf.Ray3f(torch.zeros(3, n).cuda(), torch.from_numpy(d).cuda())
+    si.sh_frame = hf.Frame3f(None, None, torch.from_numpy(sh_n).cuda().requires_grad_(True))
+    si.t = torch.from_numpy(t).cuda()
+    vt = torch.from_numpy(vis).cuda() if with_vis else None
+    img = hf.direct_lighting(si, ray, torch.from_numpy(LIGHTS.astype(np.float32)), albedo=0.7, spp=spp, vis=vt)
+    ref = oracle.direct_lighting(sh_n, d, t, LIGHTS.astype(np.float32), albedo=0.7, spp=spp, vis=vis)
+    assert np.allclose(img.detach().cpu().numpy(), ref, rtol=1e-5, atol=1e-7)
+    gi = rng.normal(size=ref.shape).astype(np.float32)
+    (img * torch.from_numpy(gi).cuda()).sum().backward()
+    gref = oracle.direct_lighting_adjoint(sh_n, d, t, LIGHTS.astype(np.float32), gi, albedo=0.7, spp=spp, vis=vis)
+    assert np.allclose(si.sh_frame.n.grad.cpu().numpy(), gref, rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.gpu
+def test_gpu_lights_to_height_gradient_chain(hf, oracle):
+    """image loss -> hf_direct_lighting_adjoint -> hf_adjoint -> dL/dheight, against the oracle's chain."""
+    import torch
+    rng = np.random.default_rng(11)
+    h = (0.5 + 0.2 * rng.uniform(-1, 1, (33, 33))).astype(np.float32)
+    shape = hf.Heightfield(heightfield=torch.from_numpy(h).cuda(), max_height=0.5)
+    shape.heightfield.requires_grad_(True)
+    rays = hf.workload.ortho_rays(32, 32, 4, "cuda", seed=0, origin=(0.6, 0.35, 2.0), target=(0.0, 0.0, 0.25), scale=(0.9, 0.9, 1.0))
+    ray = hf.Ray3f(rays[0:3], rays[3:6], rays[6])
+    si = shape.ray_intersect(ray, hf.RayFlags.All)
+    img = hf.direct_lighting(si, ray, torch.from_numpy(LIGHTS.astype(np.float32)), albedo=0.8, spp=4)
+    gi = torch.from_numpy(rng.normal(size=tuple(img.shape)).astype(np.float32)).cuda()
+    (img * gi).sum().backward()
+    r = rays.cpu().numpy()
+    f = oracle.OracleField(h, max_height=0.5)
+    t, u, v, prim = f.ray_intersect_preliminary(r)
+    rec = f.compute_surface_interaction(r, t, u, v, prim, oracle.RAY_ALL)
+    gn = oracle.direct_lighting_adjoint(rec["sh_n"], r[3:6], rec["t"], LIGHTS.astype(np.float32), gi.cpu().numpy(), albedo=0.8, spp=4)
+    gh = f.adjoint(r, t, u, v, prim, {"sh_n": gn.astype(np.float32)}, oracle.RAY_ALL)
+    got = shape.heightfield.grad.cpu().numpy()
+    assert np.linalg.norm(got - gh) <= 1e-5 * np.linalg.norm(gh) and np.linalg.norm(gh) > 0
+
+
+@pytest.mark.gpu
+def test_gpu_direct_lighting_argument_errors(hf):
+    import torch
+    si = hf.SurfaceInteraction3f(); si.sh_frame = hf.Frame3f(None, None, torch.zeros(3, 10).cuda()); si.t = torch.zeros(10).cuda()
+    ray = hf.Ray3f(torch.zeros(3, 10).cuda(), torch.zeros(3, 10).cuda())
+    with pytest.raises(hf.HfError):
+        hf.direct_lighting(si, ray, torch.ones(1, 4), spp=3)       # n not a multiple of spp
+    with pytest.raises(hf.HfError):
+        hf.direct_lighting(si, ray, torch.ones(9, 4), spp=1)       # more than HF_MAX_LIGHTS
