@@ -29,16 +29,20 @@ import hf_amd  # noqa: E402
 LIGHTS = torch.tensor([[0.5, 0.2, 0.84], [-0.5, 0.3, 0.81], [0.1, -0.6, 0.79], [0.0, 0.0, 1.0]])
 
 
-def render(shape, ray, lights, spp):
+def render(shape, ray, lights, spp, shadows=False):
     si = shape.ray_intersect(ray, hf_amd.RayFlags.All)
     valid = si.is_valid()
+    vis = None
+    if shadows:  # detached visibility of each light: one any-hit launch per light (scene.cpp:290-293)
+        with torch.no_grad():
+            vis = torch.stack([~shape.ray_test(si.spawn_ray(l[:3])) for l in lights]).to(torch.uint8)
     # diffuse direct lighting + box-filter film on the wavefront (hf_direct_lighting): [K, pixels]
-    images = hf_amd.direct_lighting(si, ray, lights, albedo=1.0, spp=spp)
+    images = hf_amd.direct_lighting(si, ray, lights, albedo=1.0, spp=spp, vis=vis)
     depth = torch.where(valid, si.t, torch.zeros_like(si.t))
     return images, depth, valid
 
 
-def run(grid=128, film=256, spp=1, steps=100, lr=0.02, device="cuda", verbose=True, seed=0):
+def run(grid=128, film=256, spp=1, steps=100, lr=0.02, device="cuda", verbose=True, seed=0, shadows=False):
     dev = torch.device(device)
     lights = torch.cat([LIGHTS / LIGHTS.norm(dim=1, keepdim=True), torch.full((len(LIGHTS), 1), math.pi)], 1)  # E = pi
     target_h = hf_amd.workload.sine_heights(grid, grid, device=dev)
@@ -48,7 +52,7 @@ def run(grid=128, film=256, spp=1, steps=100, lr=0.02, device="cuda", verbose=Tr
     ray = hf_amd.Ray3f(rays[0:3], rays[3:6], rays[6])
     target = hf_amd.Heightfield(heightfield=target_h, max_height=0.5)
     with torch.no_grad():
-        tgt_img, tgt_depth, tgt_valid = render(target, ray, lights, spp)
+        tgt_img, tgt_depth, tgt_valid = render(target, ray, lights, spp, shadows)
     shape = hf_amd.Heightfield(heightfield=torch.full_like(target_h, 0.5), max_height=0.5)
     shape.heightfield.requires_grad_(True)
     opt = hf_amd.Adam(shape, lr=lr)                       # hf_adam_step: optimizers.py:263-300 + params.update
@@ -56,7 +60,7 @@ def run(grid=128, film=256, spp=1, steps=100, lr=0.02, device="cuda", verbose=Tr
     t0 = time.perf_counter()
     for it in range(steps):
         opt.zero_grad()
-        images, depth, valid = render(shape, ray, lights, spp)
+        images, depth, valid = render(shape, ray, lights, spp, shadows)
         both = valid & tgt_valid
         loss = ((images - tgt_img) ** 2).sum(0).mean() \
             + 10.0 * (((depth - tgt_depth) ** 2) * both).sum() / both.sum()
@@ -86,5 +90,6 @@ if __name__ == "__main__":
     ap.add_argument("--spp", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--lr", type=float, default=0.02)
+    ap.add_argument("--shadows", action="store_true", help="shadow rays towards every light (one ray_test per light)")
     a = ap.parse_args()
-    run(a.grid, a.film, a.spp, a.steps, a.lr)
+    run(a.grid, a.film, a.spp, a.steps, a.lr, shadows=a.shadows)

@@ -131,6 +131,20 @@ class SurfaceInteraction3f:
     def is_valid(self):
         return self.t != math.inf
 
+    def spawn_ray(self, d):
+        """Semi-infinite ray from the interaction towards ``d`` ([3] or [3, n]); the origin is offset along
+        the detached normal by (1 + max|p|) * RayEpsilon, signed by <n, d> (interaction.h:134-136, 161-165;
+        RayEpsilon = 1500 * eps/2, math.h:18-22)."""
+        d = torch.as_tensor(d, dtype=torch.float32, device=self.p.device)
+        if d.dim() == 1:
+            d = d[:, None].expand(3, self.p.shape[1])
+        p, n = self.p.detach(), self.n.detach()
+        mag = (1.0 + p.abs().max(0).values) * (1500.0 * 5.9604644775390625e-08)
+        mag = torch.where((n * d).sum(0) < 0, -mag, mag)
+        o = torch.addcmul(p, mag[None, :], n)
+        maxt = torch.full((p.shape[1],), math.inf, dtype=torch.float32, device=p.device)
+        return Ray3f(o.contiguous(), d.contiguous(), maxt)
+
 
 # order of the differentiable SI block handed to autograd: 18 rows
 _DIFF_ROWS = [("t", 1), ("p", 3), ("n", 3), ("uv", 2), ("sh_n", 3), ("dp_du", 3), ("dp_dv", 3)]

@@ -15,3 +15,35 @@ def test_adam_recovers_heights(hf):
     hist, err, wall = inverse_heights.run(grid=64, film=128, spp=1, steps=60, lr=0.02, verbose=False)
     assert hist[-1] < 0.1 * hist[0], (hist[0], hist[-1])      # the loss drops by > 10x
     assert err < 0.12                                          # start: mean |0.5 - h*| ~ 0.17
+
+
+def test_shadowed_lighting_matches_oracle_visibility(hf, oracle):
+    """si.spawn_ray (interaction.h:134-136,161-165) + ray_test as the visibility of hf_direct_lighting:
+    the any-hit mask of the spawned shadow rays equals the oracle's, and shadowed samples are dark."""
+    import numpy as np
+    import torch
+    h = hf.workload.sine_heights(96, 96, device="cuda")
+    shape = hf.Heightfield(heightfield=h, max_height=0.5)
+    rays = hf.workload.ortho_rays(64, 64, 4, "cuda", seed=1, origin=(0.6, 0.35, 2.0), target=(0.0, 0.0, 0.25), scale=(0.9, 0.9, 1.0))
+    ray = hf.Ray3f(rays[0:3], rays[3:6], rays[6])
+    si = shape.ray_intersect(ray, hf.RayFlags.All)
+    l = torch.tensor([0.8, 0.1, 0.59]); l = l / l.norm()      # a low light: long shadows
+    sray = si.spawn_ray(l)
+    hit = shape.ray_test(sray)
+    valid = si.is_valid()
+    r = torch.cat([sray.o, sray.d, sray.maxt[None]]).cpu().numpy()
+    ok = valid.cpu().numpy()
+    f = oracle.OracleField(h.cpu().numpy(), max_height=0.5)
+    assert np.array_equal(f.ray_test(r[:, ok]), hit.cpu().numpy()[ok])
+    frac = float(hit[valid].float().mean())
+    assert 0.05 < frac < 0.95, frac                             # some samples are in shadow, some are lit
+    lights = torch.cat([l, torch.tensor([3.14159265])])[None]
+    lit = hf.direct_lighting(si, ray, lights, spp=4, vis=(~hit).to(torch.uint8)[None])
+    unshadowed = hf.direct_lighting(si, ray, lights, spp=4)
+    assert float(lit.sum()) < float(unshadowed.sum()) and float(lit.min()) >= 0
+
+
+def test_inverse_loop_with_shadows_runs(hf):
+    import inverse_heights
+    hist, err, wall = inverse_heights.run(grid=64, film=64, spp=4, steps=15, lr=0.02, verbose=False, shadows=True)
+    assert hist[-1] < hist[0]
