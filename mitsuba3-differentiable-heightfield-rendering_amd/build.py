@@ -43,5 +43,21 @@ def build(force=False, verbose=False):
     return LIB_PATH
 
 
+HOST_EXAMPLE_SRC = os.path.join(PKG_DIR, "..", "examples", "host_loop.cpp")
+HOST_EXAMPLE_BIN = os.path.join(PKG_DIR, "..", "examples", "host_loop")
+
+
+def build_host_example(verbose=False):
+    """examples/host_loop: the C ABI driven from plain C++ (links libhf.so, no Python / torch)."""
+    build()
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O2", "-std=c++17", HOST_EXAMPLE_SRC, "-o", HOST_EXAMPLE_BIN,
+           "-L", PKG_DIR, "-lhf", "-Wl,-rpath,$ORIGIN/../" + os.path.basename(PKG_DIR)]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return HOST_EXAMPLE_BIN
+
+
 if __name__ == "__main__":
     print(build(force=True, verbose=True))
+    print(build_host_example(verbose=True))

@@ -47,3 +47,13 @@ def test_inverse_loop_with_shadows_runs(hf):
     import inverse_heights
     hist, err, wall = inverse_heights.run(grid=64, film=64, spp=4, steps=15, lr=0.02, verbose=False, shadows=True)
     assert hist[-1] < hist[0]
+
+
+def test_cxx_host_drives_the_abi_without_python(hf):
+    """examples/host_loop.cpp: trace -> shade -> adjoints -> Adam through include/hf.h from plain C++
+    (built by __graft_entry__.build()); exit code 0 = the loss dropped 5x."""
+    import subprocess
+    exe = hf.build.build_host_example() if not os.path.exists(hf.build.HOST_EXAMPLE_BIN) else hf.build.HOST_EXAMPLE_BIN
+    out = subprocess.run([exe, "64", "96", "4", "60"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "mean |h - h*|" in out.stdout
