@@ -1,19 +1,23 @@
 // hf_kernels.hip -- gfx950 kernels of libhf + their launchers.
 //
 //   hf_mip_level1_kernel / hf_mip_reduce_kernel   min/max mip pyramid
+//   hf_shear_kernel                                sheared bounds of the fine levels (hf_device.h)
 //   hf_trace_kernel<MODE>                          hierarchical min/max-mip traversal:
 //        MODE 0 closest hit  -> PreliminaryIntersection   (row a1)
 //        MODE 1 any hit      -> ray_test                   (row a2)
 //        MODE 2 closest hit + fused surface interaction    (rows a1+a4)
 //   hf_si_kernel                                   compute_surface_interaction (row a4)
 //   hf_adjoint_kernel                              reverse mode of a4, atomic scatter (row a5)
+//   hf_direct_kernel / hf_direct_adjoint_kernel, hf_adam_kernel     next rows
 //
 // Traversal = depth-first walk of the implicit quadtree over the cells, children in
 // front-to-back order (the grid is mirrored so the ray direction is non-negative on
 // both axes: "order space").  One visit of an inner node fetches the (min z, max z)
 // boxes of its 4 children and keeps those the *fat* ray segment [0,t_hi] overlaps; a
 // level-1 node fetches its 3x3 heights and yields the cells whose two triangles are
-// then tested.  Pending children live in 4-bit-per-level mask stacks held in registers.
+// then tested.  On the fine levels (2..HF_SHEAR_TOP, and the 2x2-cell blocks) the boxes are
+// sheared about a plane through the node's corner heights, which is what makes them tight on
+// slopes.  Pending children live in 4-bit-per-level mask stacks held in registers.
 // The 64 rays of a coherent wave (primary rays: one pixel's samples) share the walk of
 // the upper levels -- node coordinates, masks and stack are wave-uniform and live in
 // SGPRs, a child is entered when __ballot says any lane overlaps it -- and nodes of
@@ -155,14 +159,13 @@ struct hf_quad {
 };
 
 // Overlap mask (ACTUAL numbering j = 2*jy + jx) of the fat ray segment [0,thi] with the four
-// boxes of the 2x2 block whose order-space origin is (fX,fY), box size S; tent[j] = entry
+// boxes of the 2x2 block whose order-space origin is (fX,fY), box size S.
 // parameter of box j.  The third coordinate of the ray is the line  gz + t dz  (+/- mz): the height
 // for min/max boxes, the sheared height for sheared bounds.  Direction is >= 0 in order space, so a box's entry planes are its low
 // faces and its exit planes its high faces; v_max3/v_min3 drop the NaN of 0*inf (origin of an
 // axis-parallel ray exactly on a face plane).
 __device__ __forceinline__ uint32_t child_mask(const hf_trav &r, bool fx, bool fy, float fX, float fY, float S,
-                                               const hf_quad &q, float gz, float dz, float mz, float thi,
-                                               float tent[4]) {
+                                               const hf_quad &q, float gz, float dz, float mz, float thi) {
     const float ex = fX - r.gxm, lx = fX + S - r.gxp; // entry / exit plane offsets of order column 0
     const float ey = fY - r.gym, ly = fY + S - r.gyp;
     // order-space offset of ACTUAL child column / row 0 and 1 (a mirrored axis swaps near and far half)
@@ -179,7 +182,6 @@ __device__ __forceinline__ uint32_t child_mask(const hf_trav &r, bool fx, bool f
         const float t0 = fmaxf(fmaxf(xlo, ylo), 0.f), t1 = fminf(fminf(xhi, yhi), thi);
         const float za = __builtin_fmaf(t0, dz, gz), zb = __builtin_fmaf(t1, dz, gz);
         const bool ok = (t0 <= t1) & (fminf(za, zb) - mz <= q.hi[j]) & (fmaxf(za, zb) + mz >= q.lo[j]);
-        tent[j] = t0;
         m |= ok ? (1u << j) : 0u;
     }
     return m;
@@ -318,8 +320,7 @@ __device__ __forceinline__ uint32_t block_cells(const hf_dev_field &f, const hf_
     float gz, dz, mz;
     shear_line(f, rs, fx, fy, a, b, c, __builtin_fabsf(a) + __builtin_fabsf(b), fX + 1.f, fY + 1.f, gz, dz, mz);
     mz += 1e-6f * (__builtin_fabsf(c) + __builtin_fabsf(a) + __builtin_fabsf(b)); // rounding of the w's
-    float tent[4];
-    return child_mask(r, fx, fy, fX, fY, 1.f, q, gz, dz, mz, thi, tent);
+    return child_mask(r, fx, fy, fX, fY, 1.f, q, gz, dz, mz, thi);
 }
 
 // actual-child mask -> order-space child mask (bit k = bit (k ^ flip))
@@ -329,25 +330,12 @@ __device__ __forceinline__ uint32_t to_order(uint32_t m, bool fx, bool fy) {
     return m;
 }
 
-// fetch the four child boxes of inner node (ix,iy) (ACTUAL coordinates) of level L >= 2
-__device__ __forceinline__ void load_children(const float2 *__restrict__ mip, int top, int L, uint32_t ix, uint32_t iy,
-                                              hf_quad &q) {
-    const uint32_t kd = (uint32_t) (top - (L - 1)); // depth of the children, pitch 2^kd
-    const uint32_t base = hf_depth_off((int) kd) + ((2u * iy) << kd) + 2u * ix; // even: 16-byte aligned pairs
-    const float4 a = *(const float4 *) (mip + base), b = *(const float4 *) (mip + base + (1u << kd));
-    q.lo[0] = a.x; q.hi[0] = a.y; q.lo[1] = a.z; q.hi[1] = a.w;
-    q.lo[2] = b.x; q.hi[2] = b.y; q.lo[3] = b.z; q.hi[3] = b.w;
-}
-
 // data source of the per-lane subtree walk: heights + mips straight from global memory (L1/L2)
 struct hf_src_global {
     const float2 *__restrict__ mip;
     const float4 *__restrict__ shear;
     const float *__restrict__ h;
     int top, W;
-    __device__ __forceinline__ void children(int L, uint32_t ix, uint32_t iy, hf_quad &q) const {
-        load_children(mip, top, L, ix, iy, q);
-    }
     // 32-bit byte offset from the uniform base (one scalar-base load, no 64-bit vector address maths);
     // hf_create limits the grid to 2^30 vertices
     __device__ __forceinline__ float height(int i, int j) const {
@@ -429,8 +417,7 @@ __device__ __forceinline__ bool walk_subtree(const hf_dev_field &f, const Src &s
                 q.lo[0] = q01.x; q.hi[0] = q01.y; q.lo[1] = q01.z; q.hi[1] = q01.w;
                 q.lo[2] = q23.x; q.hi[2] = q23.y; q.lo[3] = q23.z; q.hi[3] = q23.w;
             }
-            float tent[4];
-            cur = to_order(child_mask(r, fx, fy, (float) X * S, (float) Y * S, Sc, q, gz, dz, mz, thi, tent), fx, fy);
+            cur = to_order(child_mask(r, fx, fy, (float) X * S, (float) Y * S, Sc, q, gz, dz, mz, thi), fx, fy);
         }
         if (__ballot(pblk) == 0ull) break; // every lane is done
         // ---- parked blocks: 3x3 heights -> candidate cells, all parked lanes together ----
@@ -554,8 +541,7 @@ __device__ __forceinline__ void walk_packet(const hf_dev_field &f, const hf_lds_
                 q.lo[2] = b2.x; q.hi[2] = b2.y; q.lo[3] = b3.x; q.hi[3] = b3.y;
             }
             const float S = (float) (1u << (L - 1));
-            float tent[4];
-            ml = child_mask(r, fx, fy, (float) X * (S + S), (float) Y * (S + S), S, q, r.gz, r.dz, r.mz, thi, tent);
+            ml = child_mask(r, fx, fy, (float) X * (S + S), (float) Y * (S + S), S, q, r.gz, r.dz, r.mz, thi);
             uint32_t ma = 0;
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) ma |= (__ballot((ml >> jj) & 1u) != 0ull) ? (1u << jj) : 0u;
@@ -617,9 +603,6 @@ __device__ __forceinline__ void miss_si(hf_si_rec &si, v3 d, uint32_t flags) {
 
 #define HF_GRAB 512 // most rays a wave takes from the work counter per fetch (hf_grab_for)
 
-// Persistent waves: every wave pulls `grab` consecutive rays at a time from a global
-// counter (zeroed on the stream before the launch), so expensive image regions are
-// spread over all CUs whatever their position in the wavefront.
 // the one kernel argument (kernarg segment offset 0)
 struct hf_trace_args {
     hf_dev_field f;
@@ -645,6 +628,9 @@ __device__ __forceinline__ hf_dev_field load_field(const __attribute__((address_
     return f;
 }
 
+// Persistent waves: every wave pulls `grab` consecutive rays at a time from a global
+// counter (zeroed on the stream before the launch), so expensive image regions are
+// spread over all CUs whatever their position in the wavefront.
 template <int MODE>
 __global__ __launch_bounds__(HF_BLOCK, 4) void hf_trace_kernel(hf_trace_args a) {
     const hf_dev_field &f = a.f;
