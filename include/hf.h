@@ -248,6 +248,38 @@ int hf_direct_lighting_adjoint(size_t n, uint32_t spp, const float *const sh_n[3
                                const uint8_t *const *vis, const float *grad_image, float *const grad_sh_n[3],
                                hf_stream_t stream);
 
+/* ---- next row: warped-area reparameterisation of rays ---------- */
+
+/* The auxiliary-ray machinery of mitsuba.ad.reparameterize_ray (src/python/python/ad/reparam.py:10-123,
+ * 224-333; Bangaru et al. 2020) for a scene that is this one shape, split into the two per-sample kernels
+ * its three loops are made of; the auxiliary rays themselves are traced by hf_ray_intersect with
+ * HF_RAY_ALL | HF_RAY_FOLLOWSHAPE | HF_RAY_BOUNDARYTEST (reparam.py:93-95) and the gradient of an
+ * auxiliary hit reaches the heights through hf_adjoint with the same flags.
+ * Random numbers: the reference draws two PCG32 floats per auxiliary ray (reparam.py:186); PCG32 lives in
+ * the absent Dr.Jit, so sample (k, lane i) is sample_tea_32(seed + pair, i) (include/mitsuba/core/random.h:76-91)
+ * -> two 23-bit floats, pair = k/2 with antithetic sampling (the even iteration of a pair reuses the
+ * sample with omega_local.xy negated, reparam.py:83-85,188-190), else k.
+ *
+ * hf_reparam_aux_rays: auxiliary ray k of every primary ray (o, d; d unit length): direction =
+ * Frame3f(d).to_world(square_to_von_mises_fisher(sample, kappa)) (warp.h:546-583, frame.h:39-41,
+ * vector.h:116-136), origin o, maxt = inf; inactive lanes get maxt = -1 (a miss). kappa > 0. */
+int hf_reparam_aux_rays(size_t n, const float *const o[3], const float *const d[3], const uint8_t *active,
+                        uint32_t k, float kappa, int antithetic, uint32_t seed, float *const aux_d[3],
+                        float *aux_maxt, hf_stream_t stream);
+/* hf_reparam_weights, mode 0 (reparam.py:97-121, first loop of backward :224-256): from the auxiliary hit
+ * (si_t, si_boundary_test) the harmonic weight w = (1 / (D - 1 + B))^exponent * D and its tangential
+ * gradient d_w_omega; accumulates Z[n] += w, dZ[3][n] += d_w_omega.
+ * mode 1 (third loop :283-325 for the shape parameter): with the totals Z, dZ and the upstream gradients of
+ * the outputs, grad_direction[3][n] and grad_divergence[n] (reparam.py:262-281: direction =
+ * normalize(d + V / Z), divergence = (div - <V / Z, dZ>) / Z at V = 0), the gradient of this sample's
+ * V_direct = (si.p - o) / si.t is written as upstream gradient of the auxiliary hit: grad_p[3][n] and
+ * grad_t[n] (zero for misses), to be handed to hf_adjoint as hf_si_grad_t {p, t} with HF_RAY_FOLLOWSHAPE. */
+int hf_reparam_weights(int mode, size_t n, const float *const o[3], const float *const d[3],
+                       const uint8_t *active, uint32_t k, float kappa, float exponent, int antithetic,
+                       uint32_t seed, const float *si_t, const float *const si_p[3], const float *si_boundary_test,
+                       float *Z, float *const dZ[3], const float *const grad_direction[3],
+                       const float *grad_divergence, float *const grad_p[3], float *grad_t, hf_stream_t stream);
+
 /* ---- introspection (tests / tools) --------------------------------------------- */
 int hf_num_levels(const hf_field_t *hf);
 /* copies mip level `level` (1..num_levels) to HOST memory as (min,max) pairs,

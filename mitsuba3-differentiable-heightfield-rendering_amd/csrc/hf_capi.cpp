@@ -396,3 +396,51 @@ extern "C" int hf_direct_lighting_adjoint(size_t n, uint32_t spp, const float *c
     HF_HIP(hipGetLastError());
     return HF_OK;
 }
+
+// ---- warped-area reparameterisation --------------------------------------------
+static bool all3(const float *const p[3]) { return p && p[0] && p[1] && p[2]; }
+
+extern "C" int hf_reparam_aux_rays(size_t n, const float *const o[3], const float *const d[3], const uint8_t *active,
+                                   uint32_t k, float kappa, int antithetic, uint32_t seed, float *const aux_d[3],
+                                   float *aux_maxt, hf_stream_t stream) {
+    if (!all3(o) || !all3(d) || !aux_d || !aux_d[0] || !aux_d[1] || !aux_d[2] || !aux_maxt)
+        return fail(HF_EINVAL, "hf_reparam_aux_rays: NULL argument");
+    if (!(kappa > 0.f)) return fail(HF_EINVAL, "hf_reparam_aux_rays: kappa must be > 0");
+    if (n >= ((size_t) 1 << 32)) return fail(HF_EINVAL, "hf_reparam_aux_rays: more than 2^32 rays");
+    hf_reparam_args a = {};
+    a.n = n; a.active = active; a.k = k; a.seed = seed; a.kappa = kappa; a.antithetic = antithetic;
+    for (int c = 0; c < 3; ++c) { a.o[c] = o[c]; a.d[c] = d[c]; a.aux_d[c] = aux_d[c]; }
+    a.aux_maxt = aux_maxt;
+    hf_launch_reparam_aux(a, (hipStream_t) stream);
+    HF_HIP(hipGetLastError());
+    return HF_OK;
+}
+
+extern "C" int hf_reparam_weights(int mode, size_t n, const float *const o[3], const float *const d[3],
+                                  const uint8_t *active, uint32_t k, float kappa, float exponent, int antithetic,
+                                  uint32_t seed, const float *si_t, const float *const si_p[3],
+                                  const float *si_boundary_test, float *Z, float *const dZ[3],
+                                  const float *const grad_direction[3], const float *grad_divergence,
+                                  float *const grad_p[3], float *grad_t, hf_stream_t stream) {
+    if (!all3(o) || !all3(d) || !si_t || !si_boundary_test || !Z || !dZ || !dZ[0] || !dZ[1] || !dZ[2])
+        return fail(HF_EINVAL, "hf_reparam_weights: NULL argument");
+    if (mode != 0 && mode != 1) return fail(HF_EINVAL, "hf_reparam_weights: mode must be 0 or 1");
+    if (mode == 1 && (!all3(si_p) || !all3(grad_direction) || !grad_divergence || !grad_p || !grad_p[0] || !grad_p[1] ||
+                      !grad_p[2] || !grad_t))
+        return fail(HF_EINVAL, "hf_reparam_weights: mode 1 needs si_p, grad_direction, grad_divergence, grad_p, grad_t");
+    if (!(kappa > 0.f)) return fail(HF_EINVAL, "hf_reparam_weights: kappa must be > 0");
+    if (n >= ((size_t) 1 << 32)) return fail(HF_EINVAL, "hf_reparam_weights: more than 2^32 rays");
+    hf_reparam_args a = {};
+    a.n = n; a.active = active; a.k = k; a.seed = seed; a.kappa = kappa; a.exponent = exponent;
+    a.antithetic = antithetic; a.mode = mode;
+    a.si_t = si_t; a.si_bt = si_boundary_test; a.Z = Z; a.g_div = grad_divergence; a.g_t = grad_t;
+    for (int c = 0; c < 3; ++c) {
+        a.o[c] = o[c]; a.d[c] = d[c]; a.dZ[c] = dZ[c];
+        a.si_p[c] = si_p ? si_p[c] : nullptr;
+        a.g_dir[c] = grad_direction ? grad_direction[c] : nullptr;
+        a.g_p[c] = grad_p ? grad_p[c] : nullptr;
+    }
+    hf_launch_reparam_weights(a, (hipStream_t) stream);
+    HF_HIP(hipGetLastError());
+    return HF_OK;
+}

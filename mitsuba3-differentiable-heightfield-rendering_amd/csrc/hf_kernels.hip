@@ -1132,3 +1132,115 @@ void hf_launch_direct_adjoint(size_t n, uint32_t spp, const float *const sh_n[3]
     hipLaunchKernelGGL(hf_direct_adjoint_kernel, dim3((unsigned) blocks), dim3(HF_BLOCK), 0, stream, n, spp, sn, dd, t,
                        lights, grad_image, gn);
 }
+
+// ---------------------------------------------------------------------------------
+// Warped-area reparameterisation (include/hf.h; reparam.py:10-123,224-333): per-sample kernels
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ void tea32(uint32_t v0, uint32_t v1, uint32_t &o0, uint32_t &o1) { // random.h:76-91
+    uint32_t sum = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        sum += 0x9e3779b9u;
+        v0 += ((v1 << 4) + 0xa341316cu) ^ (v1 + sum) ^ ((v1 >> 5) + 0xc8013ea4u);
+        v1 += ((v0 << 4) + 0xad90777du) ^ (v0 + sum) ^ ((v0 >> 5) + 0x7e95761eu);
+    }
+    o0 = v0; o1 = v1;
+}
+
+struct hf_aux_sample {
+    v3 omega;     // square_to_von_mises_fisher(sample, kappa), xy negated on the flipped half of a pair
+    float sy;     // sample.y
+    v3 fs, ft;    // Frame3f(d): s, t (n = d)
+};
+__device__ __forceinline__ void aux_sample(const hf_reparam_args &a, size_t i, v3 d, hf_aux_sample &q) {
+    const uint32_t pair = a.antithetic ? (a.k >> 1) : a.k;
+    uint32_t r0, r1;
+    tea32(a.seed + pair, (uint32_t) i, r0, r1);
+    const float sx = (float) (r0 >> 9) * (1.0f / 8388608.0f), sy = (float) (r1 >> 9) * (1.0f / 8388608.0f);
+    // warp.h:557-566
+    const float syc = fmaxf(1.f - sy, 1e-6f);
+    const float cos_theta = 1.f + logf(__builtin_fmaf(1.f - syc, expf(-2.f * a.kappa), syc)) / a.kappa;
+    float sn, cs;
+    sincosf(6.283185307179586f * sx, &sn, &cs);
+    const float sin_theta = __builtin_sqrtf(fmaxf(1.f - cos_theta * cos_theta, 0.f));
+    const bool flip = a.antithetic && ((a.k & 1u) == 0u); // reparam.py:83-85,189
+    q.omega = mk3(flip ? -(cs * sin_theta) : cs * sin_theta, flip ? -(sn * sin_theta) : sn * sin_theta, cos_theta);
+    q.sy = sy;
+    coordinate_system(d, q.fs, q.ft);
+}
+// Frame3f::to_world (frame.h:39-41)
+__device__ __forceinline__ v3 frame_to_world(const hf_aux_sample &q, v3 n, v3 v) {
+    return mk3(__builtin_fmaf(n.x, v.z, __builtin_fmaf(q.ft.x, v.y, q.fs.x * v.x)),
+               __builtin_fmaf(n.y, v.z, __builtin_fmaf(q.ft.y, v.y, q.fs.y * v.x)),
+               __builtin_fmaf(n.z, v.z, __builtin_fmaf(q.ft.z, v.y, q.fs.z * v.x)));
+}
+
+__global__ __launch_bounds__(HF_BLOCK) void hf_reparam_aux_kernel(hf_reparam_args a) {
+    const size_t i = (size_t) blockIdx.x * HF_BLOCK + threadIdx.x;
+    if (i >= a.n) return;
+    const v3 d = mk3(a.d[0][i], a.d[1][i], a.d[2][i]);
+    hf_aux_sample q;
+    aux_sample(a, i, d, q);
+    const v3 ad = frame_to_world(q, d, q.omega);
+    a.aux_d[0][i] = ad.x; a.aux_d[1][i] = ad.y; a.aux_d[2][i] = ad.z;
+    a.aux_maxt[i] = (a.active && a.active[i] == 0) ? -1.f : __builtin_inff();
+}
+
+__global__ __launch_bounds__(HF_BLOCK) void hf_reparam_weight_kernel(hf_reparam_args a) {
+    const size_t i = (size_t) blockIdx.x * HF_BLOCK + threadIdx.x;
+    if (i >= a.n) return;
+    const bool act = !(a.active && a.active[i] == 0);
+    const v3 o = mk3(a.o[0][i], a.o[1][i], a.o[2][i]), d = mk3(a.d[0][i], a.d[1][i], a.d[2][i]);
+    hf_aux_sample q;
+    aux_sample(a, i, d, q);
+    const float t = a.si_t[i];
+    const bool hit = act && (t != __builtin_inff());
+    // reparam.py:103-121
+    const float B = hit ? a.si_bt[i] : 1.0f;
+    const float inv_vmf = 1.0f / __builtin_fmaf(q.sy, expf(-2.f * a.kappa), 1.f - q.sy);
+    const float w_denom = inv_vmf - 1.f + B;
+    const float w_rcp = (w_denom > 1e-4f) ? 1.0f / w_denom : 0.f;
+    const float w = powf(w_rcp, a.exponent) * inv_vmf;
+    const float tmp1 = fminf(fmaxf(inv_vmf * w * w_rcp * a.kappa * a.exponent, -1e10f), 1e10f);
+    const v3 tmp2 = frame_to_world(q, d, mk3(q.omega.x, q.omega.y, 0.f));
+    const v3 dw = mk3(tmp1 * tmp2.x, tmp1 * tmp2.y, tmp1 * tmp2.z);
+    if (a.mode == 0) {
+        if (!act) return;
+        a.Z[i] += w;
+        a.dZ[0][i] += dw.x; a.dZ[1][i] += dw.y; a.dZ[2][i] += dw.z;
+        return;
+    }
+    v3 gp = mk3(0.f, 0.f, 0.f);
+    float gt = 0.f;
+    if (hit) {
+        // backward of direction = normalize(d + V/Z), divergence = (div - <V/Z, dZ>) / Z at V = 0 (reparam.py:262-281)
+        const float Z = fmaxf(a.Z[i], 1e-8f), iZ = 1.0f / Z;
+        const v3 gd = mk3(a.g_dir[0][i], a.g_dir[1][i], a.g_dir[2][i]);
+        const float gdiv = a.g_div[i];
+        const float dd = dot3(d, d), idn = 1.0f / __builtin_sqrtf(dd);
+        const float pr = dot3(d, gd) / dd;
+        const v3 dZ = mk3(a.dZ[0][i], a.dZ[1][i], a.dZ[2][i]);
+        const float c = gdiv * iZ * iZ;
+        const v3 gV = mk3((gd.x - d.x * pr) * idn * iZ - c * dZ.x, (gd.y - d.y * pr) * idn * iZ - c * dZ.y,
+                          (gd.z - d.z * pr) * idn * iZ - c * dZ.z);
+        const float gdivV = gdiv * iZ;
+        // this sample: V_i = w V_direct, div_i = <d_w_omega, V_direct>, V_direct = (p - o) / t
+        const v3 gVd = mk3(__builtin_fmaf(w, gV.x, gdivV * dw.x), __builtin_fmaf(w, gV.y, gdivV * dw.y),
+                           __builtin_fmaf(w, gV.z, gdivV * dw.z));
+        const v3 po = mk3(a.si_p[0][i] - o.x, a.si_p[1][i] - o.y, a.si_p[2][i] - o.z);
+        const float it = 1.0f / t;
+        gp = mk3(gVd.x * it, gVd.y * it, gVd.z * it);
+        gt = -dot3(gVd, po) * it * it;
+    }
+    a.g_p[0][i] = gp.x; a.g_p[1][i] = gp.y; a.g_p[2][i] = gp.z;
+    a.g_t[i] = gt;
+}
+
+void hf_launch_reparam_aux(const hf_reparam_args &a, hipStream_t stream) {
+    if (a.n == 0) return;
+    hipLaunchKernelGGL(hf_reparam_aux_kernel, dim3((unsigned) ((a.n + HF_BLOCK - 1) / HF_BLOCK)), dim3(HF_BLOCK), 0, stream, a);
+}
+void hf_launch_reparam_weights(const hf_reparam_args &a, hipStream_t stream) {
+    if (a.n == 0) return;
+    hipLaunchKernelGGL(hf_reparam_weight_kernel, dim3((unsigned) ((a.n + HF_BLOCK - 1) / HF_BLOCK)), dim3(HF_BLOCK), 0, stream, a);
+}

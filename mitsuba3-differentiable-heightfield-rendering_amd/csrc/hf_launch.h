@@ -28,3 +28,18 @@ void hf_launch_direct(size_t n, uint32_t spp, const float *const sh_n[3], const 
 void hf_launch_direct_adjoint(size_t n, uint32_t spp, const float *const sh_n[3], const float *const d[3],
                               const float *t, const hf_lights_dev &lights, const float *grad_image,
                               float *const grad_sh_n[3], hipStream_t stream);
+struct hf_reparam_args {
+    size_t n;
+    const float *o[3], *d[3];
+    const uint8_t *active;
+    uint32_t k, seed;
+    float kappa, exponent;
+    int antithetic, mode;
+    float *aux_d[3], *aux_maxt;                       // aux-ray generation
+    const float *si_t, *si_p[3], *si_bt;              // auxiliary hit
+    float *Z, *dZ[3];                                 // mode 0: accumulated, mode 1: read
+    const float *g_dir[3], *g_div;                    // mode 1
+    float *g_p[3], *g_t;                              // mode 1 outputs
+};
+void hf_launch_reparam_aux(const hf_reparam_args &a, hipStream_t stream);
+void hf_launch_reparam_weights(const hf_reparam_args &a, hipStream_t stream);

@@ -594,3 +594,102 @@ def direct_lighting(si, ray, lights, albedo=1.0, spp=1, vis=None):
     ``hf_adjoint`` and the heights."""
     lights = torch.as_tensor(lights, dtype=torch.float32)
     return _DirectLightingOp.apply(si.sh_frame.n, ray.d, si.t, lights, float(albedo), int(spp), vis)
+
+
+def _p3(x):
+    return (C.c_void_p * 3)(x[0].data_ptr(), x[1].data_ptr(), x[2].data_ptr())
+
+
+class _ReparameterizeOp(torch.autograd.Function):
+    """reparam.py:126-333 for a scene that is one heightfield: identity in primal mode, the warped-area
+    gradient of (direction, determinant) with respect to the heights in backward mode."""
+
+    @staticmethod
+    def forward(ctx, heightfield, shape, ray, num_rays, kappa, exponent, antithetic, seed, active):
+        ctx.shape, ctx.ray = shape, ray
+        ctx.cfg = (int(num_rays), float(kappa), float(exponent), bool(antithetic), int(seed), active)
+        n = ray.o.shape[1]
+        return ray.d.detach().clone(), torch.ones(n, dtype=torch.float32, device=ray.o.device)
+
+    @staticmethod
+    def backward(ctx, grad_direction, grad_divergence):
+        shape, ray = ctx.shape, ctx.ray
+        num_rays, kappa, exponent, antithetic, seed, active = ctx.cfg
+        L = _capi.lib()
+        dev = ray.o.device
+        n = ray.o.shape[1]
+        o = ray.o.detach().to(torch.float32).contiguous(); d = ray.d.detach().to(torch.float32).contiguous()
+        gd = grad_direction.to(torch.float32).contiguous(); gdiv = grad_divergence.to(torch.float32).contiguous()
+        act = None if active is None else active.to(torch.uint8).contiguous()
+        act_p = None if act is None else act.data_ptr()
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        flags = int(RayFlags.All | RayFlags.FollowShape | RayFlags.BoundaryTest)
+        aux_d = torch.empty_like(d); aux_maxt = torch.empty(n, dtype=torch.float32, device=dev)
+        Z = torch.zeros(n, dtype=torch.float32, device=dev); dZ = torch.zeros((3, n), dtype=torch.float32, device=dev)
+        g_p = torch.empty((3, n), dtype=torch.float32, device=dev); g_t = torch.empty(n, dtype=torch.float32, device=dev)
+        grad_h = torch.zeros((shape.height, shape.width), dtype=torch.float32, device=dev)
+        o_p, d_p, ad_p, dZ_p, gd_p, gp_p = _p3(o), _p3(d), _p3(aux_d), _p3(dZ), _p3(gd), _p3(g_p)
+        r_s = shape._rays_struct(o, aux_d, aux_maxt)
+        g_s = _capi.hf_si_grad_t()
+        g_s.t = g_t.data_ptr()
+        for c in range(3):
+            g_s.p[c] = g_p[c].data_ptr()
+        # The auxiliary hits of the first loop (36 B per ray and sample: pi + si.t, si.p, si.boundary_test) are kept
+        # for the second one when they fit; the reference re-traces (reparam.py:296-325), which is the fallback.
+        keep = 36 * n * num_rays <= (16 << 30)
+        bufs = [torch.empty((9, n), dtype=torch.float32, device=dev) for _ in range(num_rays if keep else 1)]
+
+        def structs(buf):
+            rows = _rows(buf, n)   # si.t, si.p[3], boundary_test | pi.t, u, v, prim_index
+            si_s = _capi.hf_si_t()
+            si_s.t = rows[0]
+            for c in range(3):
+                si_s.p[c] = rows[1 + c]
+            si_s.boundary_test = rows[4]
+            pi_s = _capi.hf_pi_t()
+            pi_s.t, pi_s.prim_uv[0], pi_s.prim_uv[1], pi_s.prim_index = rows[5], rows[6], rows[7], rows[8]
+            return rows, si_s, pi_s
+
+        def aux(k):
+            check(L.hf_reparam_aux_rays(n, C.byref(o_p), C.byref(d_p), act_p, k, kappa, int(antithetic), seed,
+                                        C.byref(ad_p), aux_maxt.data_ptr(), stream))
+
+        def trace(k, buf):
+            aux(k)
+            rows, si_s, pi_s = structs(buf)
+            check(L.hf_ray_intersect(shape._h, n, C.byref(r_s), flags, None, C.byref(pi_s), C.byref(si_s), stream))
+
+        def weights(mode, k, buf):
+            rows = _rows(buf, n)
+            sp_p = (C.c_void_p * 3)(*rows[1:4])
+            check(L.hf_reparam_weights(mode, n, C.byref(o_p), C.byref(d_p), act_p, k, kappa, exponent, int(antithetic),
+                                       seed, rows[0], C.byref(sp_p), rows[4], Z.data_ptr(), C.byref(dZ_p), C.byref(gd_p),
+                                       gdiv.data_ptr(), C.byref(gp_p), g_t.data_ptr(), stream))
+
+        for k in range(num_rays):           # weight normalisation (reparam.py:236-256)
+            buf = bufs[k if keep else 0]
+            trace(k, buf); weights(0, k, buf)
+        for k in range(num_rays):           # back-propagation of every sample (reparam.py:296-325)
+            buf = bufs[k if keep else 0]
+            if keep:
+                aux(k)                      # hf_adjoint needs the auxiliary ray again, not its trace
+            else:
+                trace(k, buf)
+            weights(1, k, buf)
+            rows, si_s, pi_s = structs(buf)
+            check(L.hf_adjoint(shape._h, n, C.byref(r_s), C.byref(pi_s), flags, None, C.byref(g_s),
+                               grad_h.data_ptr(), None, None, stream))
+        gh = grad_h
+        hf = ctx.needs_input_grad[0]
+        if gh.shape != shape.heightfield.shape:
+            gh = gh.reshape(shape.heightfield.shape)
+        return (gh if hf else None), None, None, None, None, None, None, None, None
+
+
+def reparameterize_ray(shape, ray, num_rays=4, kappa=1e5, exponent=3.0, antithetic=False, seed=0, active=None):
+    """``mitsuba.ad.reparameterize_ray`` (reparam.py:336-420) for a scene made of this heightfield: returns
+    ``(direction, det)`` = ``(ray.d, 1)`` whose gradients flow into ``shape.heightfield`` through ``num_rays``
+    auxiliary rays per ray (von Mises-Fisher around ``ray.d``, harmonic weights from ``si.boundary_test``,
+    hits followed with ``RayFlags.FollowShape``).  ``ray.d`` must be unit length.  Gradients with respect to
+    the ray itself are not propagated; PCG32 is replaced by sample_tea_32(seed, ...) (include/hf.h)."""
+    return _ReparameterizeOp.apply(shape.heightfield, shape, ray, num_rays, kappa, exponent, antithetic, seed, active)

@@ -286,3 +286,152 @@ def direct_lighting_adjoint(sh_n, d, t, lights, grad_image, albedo=1.0, spp=1, v
             w = w * (np.asarray(vis[k]) != 0)
         g += w[None, :] * L[:3, None]
     return g
+
+
+# ---------------------------------------------------------------------------------------------------
+# Warped-area reparameterisation of rays for a scene that is this one shape: float64 restatement of
+# src/python/python/ad/reparam.py:10-123 (_sample_warp_field) and :151-333 (forward / backward of
+# _ReparameterizeOp).  Random numbers: sample_tea_32(seed + pair, lane) -> two 23-bit floats, the documented
+# stand-in for the PCG32 of the absent Dr.Jit (see include/hf.h).
+# ---------------------------------------------------------------------------------------------------
+def _tea32_np(v0, v1, rounds=4):
+    v0 = np.asarray(v0, np.uint64) & 0xFFFFFFFF; v1 = np.asarray(v1, np.uint64) & 0xFFFFFFFF
+    M = np.uint64(0xFFFFFFFF); s = np.uint64(0)
+    for _ in range(rounds):
+        s = (s + np.uint64(0x9E3779B9)) & M
+        v0 = (v0 + ((((v1 << np.uint64(4)) & M) + np.uint64(0xA341316C)) ^ ((v1 + s) & M) ^ (((v1 >> np.uint64(5)) + np.uint64(0xC8013EA4)) & M))) & M
+        v1 = (v1 + ((((v0 << np.uint64(4)) & M) + np.uint64(0xAD90777D)) ^ ((v0 + s) & M) ^ (((v0 >> np.uint64(5)) + np.uint64(0x7E95761E)) & M))) & M
+    return v0, v1
+
+
+def _coordinate_system_np(n):
+    """include/mitsuba/core/vector.h:116-136"""
+    sign = np.where(n[2] >= 0, 1.0, -1.0)
+    a = -1.0 / (sign + n[2]); b = n[0] * n[1] * a
+    ms = lambda x: np.where(n[2] >= 0, x, -x)
+    s = np.stack([ms(n[0] * n[0] * a) + 1.0, ms(b), ms(-n[0])])
+    t = np.stack([b, n[1] * n[1] * a + sign, -n[1]])
+    return s, t
+
+
+def reparam_aux_sample(d, k, kappa, antithetic=False, seed=0):
+    """omega_local, sample.y and the frame of auxiliary ray k of every primary direction d [3,n] (float32 inputs,
+    float64 maths): warp.h:557-566, reparam.py:80-90."""
+    d = np.asarray(d, np.float32).astype(np.float64)
+    n = d.shape[1]
+    pair = (k >> 1) if antithetic else k
+    r0, r1 = _tea32_np(np.full(n, (seed + pair) & 0xFFFFFFFF, np.uint64), np.arange(n, dtype=np.uint64))
+    f = np.float32
+    sx = (np.float32(r0 >> np.uint64(9)) * f(1.0 / 8388608.0)).astype(f); sy = (np.float32(r1 >> np.uint64(9)) * f(1.0 / 8388608.0)).astype(f)
+    # warp.h:557-566 in float32, one rounding per operation: 1 - cos_theta^2 cancels, so sin_theta carries the
+    # rounding of cos_theta -- the reference's Float does the same
+    syc = np.maximum(f(1) - sy, f(1e-6)).astype(f)
+    cos_t = (f(1) + (np.log(((f(1) - syc) * np.exp(f(-2.0) * f(kappa)) + syc).astype(f)).astype(f) / f(kappa)).astype(f)).astype(f)
+    sin_t = np.sqrt(np.maximum(f(1) - (cos_t * cos_t).astype(f), f(0))).astype(f)
+    ang = (f(6.283185307179586) * sx).astype(f)
+    om = np.stack([(np.cos(ang).astype(f) * sin_t).astype(f), (np.sin(ang).astype(f) * sin_t).astype(f), cos_t]).astype(np.float64)
+    sy = sy.astype(np.float64)
+    if antithetic and (k & 1) == 0:
+        om[0] = -om[0]; om[1] = -om[1]
+    fs, ft = _coordinate_system_np(d)
+    return om, sy, fs, ft
+
+
+def reparam_aux_rays(o, d, k, kappa, antithetic=False, seed=0, active=None):
+    """[7,n] float32 auxiliary rays (reparam.py:87-90); inactive lanes get maxt = -1."""
+    o = np.asarray(o, np.float32); d = np.asarray(d, np.float32)
+    om, sy, fs, ft = reparam_aux_sample(d, k, kappa, antithetic, seed)
+    ad = fs * om[0] + ft * om[1] + d.astype(np.float64) * om[2]
+    maxt = np.full(o.shape[1], np.inf)
+    if active is not None:
+        maxt[np.asarray(active) == 0] = -1.0
+    return np.concatenate([o, ad, maxt[None]]).astype(np.float32)
+
+
+def _reparam_weight(d, k, kappa, exponent, antithetic, seed, t, bt):
+    """reparam.py:97-121.  The weight is (1 / (D - 1 + B))^exponent * D with D - 1 + B down to 1e-4: it is
+    evaluated in float32, one rounding per operation in the reference's order, like Dr.Jit's Float does."""
+    f = np.float32
+    om, sy, fs, ft = reparam_aux_sample(d, k, kappa, antithetic, seed)
+    hit = np.isfinite(t)
+    B = np.where(hit, bt, 1.0).astype(f)
+    sy32 = sy.astype(f)
+    inv_vmf = (f(1) / (sy32 * np.exp(f(-2.0) * f(kappa)) + (f(1) - sy32)).astype(f)).astype(f)
+    w_denom = ((inv_vmf - f(1)) + B).astype(f)
+    ok = w_denom > f(1e-4)
+    w_rcp = np.where(ok, f(1) / np.where(ok, w_denom, f(1)), f(0)).astype(f)
+    w = (np.power(w_rcp, f(exponent)).astype(f) * inv_vmf).astype(f)
+    tmp1 = np.clip((((inv_vmf * w).astype(f) * w_rcp).astype(f) * f(kappa)).astype(f) * f(exponent), f(-1e10), f(1e10)).astype(f)
+    tmp2 = (fs * om[0] + ft * om[1]).astype(f)
+    dw = (tmp1 * tmp2).astype(f)
+    return hit, w.astype(np.float64), dw.astype(np.float64)
+
+
+def reparam_backward(field, o, d, grad_direction, grad_divergence, num_rays=4, kappa=1e5, exponent=3.0,
+                     antithetic=False, seed=0, active=None, nthreads=0):
+    """dL/dheight through reparameterize_ray (reparam.py:224-333, backward_symbolic, shape parameter only):
+    given the upstream gradients of its outputs (direction [3,n], divergence [n])."""
+    o = np.asarray(o, np.float32); d = np.asarray(d, np.float32)
+    n = o.shape[1]
+    act = np.ones(n, bool) if active is None else (np.asarray(active) != 0)
+    flags = RAY_ALL | 0x80 | 0x40
+    Z = np.zeros(n); dZ = np.zeros((3, n)); recs = []
+    for k in range(num_rays):                                     # first loop: Z, dZ
+        r = reparam_aux_rays(o, d, k, kappa, antithetic, seed, active)
+        t, u, v, prim = field.ray_intersect_preliminary(r, nthreads=nthreads)
+        si = field.compute_surface_interaction(r, t, u, v, prim, flags, nthreads=nthreads)
+        hit, w, dw = _reparam_weight(d, k, kappa, exponent, antithetic, seed, si["t"].astype(np.float64), si["boundary_test"].astype(np.float64))
+        Z += np.where(act, w, 0.0); dZ += np.where(act, dw, 0.0)
+        recs.append((r, t, u, v, prim, si, hit & act, w, dw))
+    Z = np.maximum(Z, 1e-8)
+    dd = d.astype(np.float64); gd = np.asarray(grad_direction, np.float64); gdiv = np.asarray(grad_divergence, np.float64)
+    n2 = (dd * dd).sum(0)
+    gV = (gd - dd * ((dd * gd).sum(0) / n2)) / np.sqrt(n2) / Z - gdiv / (Z * Z) * dZ
+    gdivV = gdiv / Z
+    gh = np.zeros((field.H, field.W), np.float64)
+    for (r, t, u, v, prim, si, hit, w, dw) in recs:               # third loop: back-propagate every sample
+        gVd = w * gV + gdivV * dw
+        tt = np.where(hit, si["t"].astype(np.float64), 1.0)
+        po = si["p"].astype(np.float64) - o.astype(np.float64)
+        gp = np.where(hit, gVd / tt, 0.0)
+        gt = np.where(hit, -(gVd * po).sum(0) / (tt * tt), 0.0)
+        gh += field.adjoint(r, t, u, v, prim, {"p": gp.astype(np.float32), "t": gt.astype(np.float32)[None]}, flags, nthreads=nthreads)
+    return gh
+
+
+def reparam_forward(field, o, d, dheights, num_rays=4, kappa=1e5, exponent=3.0, antithetic=False, seed=0, active=None):
+    """Forward mode (reparam.py:151-220) for a height perturbation dheights [H,W]: returns (V_theta [3,n],
+    div_V_theta [n]).  dV_direct/dtheta for a FollowShape hit: d(p)/dtheta = sum_k b_k s zhat_world dh_k,
+    V_direct = (p - o)/t with t = |p - o| (unit auxiliary direction)."""
+    o = np.asarray(o, np.float32); d = np.asarray(d, np.float32)
+    n = o.shape[1]
+    act = np.ones(n, bool) if active is None else (np.asarray(active) != 0)
+    flags = RAY_ALL | 0x80 | 0x40
+    Z = np.zeros(n); dZ = np.zeros((3, n)); gradV = np.zeros((3, n)); graddiv = np.zeros(n)
+    zw = np.asarray(field.to_world, np.float64).reshape(3, 4)[:, 2] * field.max_height
+    dh = np.asarray(dheights, np.float64)
+    for k in range(num_rays):
+        r = reparam_aux_rays(o, d, k, kappa, antithetic, seed, active)
+        t, u, v, prim = field.ray_intersect_preliminary(r)
+        si = field.compute_surface_interaction(r, t, u, v, prim, flags)
+        hit, w, dw = _reparam_weight(d, k, kappa, exponent, antithetic, seed, si["t"].astype(np.float64), si["boundary_test"].astype(np.float64))
+        hit = hit & act
+        # vertices of the hit triangles and their barycentric weights
+        cell = (prim >> 1).astype(np.int64); tri = (prim & 1).astype(np.int64)
+        cy, cx = cell // (field.W - 1), cell % (field.W - 1)
+        vi = np.where(tri == 0, np.stack([cy, cy, cy + 1]), np.stack([cy + 1, cy + 1, cy]))
+        vj = np.where(tri == 0, np.stack([cx, cx + 1, cx]), np.stack([cx + 1, cx, cx + 1]))
+        b1, b2 = u.astype(np.float64), v.astype(np.float64); bw = np.stack([1 - b1 - b2, b1, b2])
+        vi = np.where(hit, vi, 0); vj = np.where(hit, vj, 0)
+        dz = (bw * dh[vi, vj]).sum(0)                               # d(height of p)/dtheta in height units
+        dp = zw[:, None] * dz[None, :]
+        po = si["p"].astype(np.float64) - o.astype(np.float64)
+        tt = np.where(hit, si["t"].astype(np.float64), 1.0)
+        dt = (po * dp).sum(0) / tt                                  # t = |p - o|
+        dVd = np.where(hit, dp / tt - po * dt / (tt * tt), 0.0)
+        Z += np.where(act, w, 0.0); dZ += np.where(act, dw, 0.0)
+        gradV += w * dVd; graddiv += (dw * dVd).sum(0)
+    iZ = 1.0 / np.maximum(Z, 1e-8)
+    Vt = gradV * iZ
+    div = (graddiv - (Vt * dZ).sum(0)) * iZ
+    return np.where(act, Vt, 0.0), np.where(act, div, 0.0)

@@ -55,6 +55,16 @@ if any(k.startswith("sec") for k in a.kinds):
     nrays = {"sec_fwd": Rs, "sec_test": Rs}
 else:
     nrays = {}
+if "reparam" in a.kinds:
+    # backward of reparameterize_ray (4 auxiliary rays per primary ray: 8 fused traces + 8 weight kernels + 4 adjoints)
+    hfp = shape.heightfield.requires_grad_(True)
+    ray_o = hf_amd.Ray3f(rays[0:3], rays[3:6], rays[6])
+    gdir = torch.randn(3, R, device=dev); gdv = torch.randn(R, device=dev)
+    def _reparam():
+        shape.heightfield.grad = None
+        dd, det = hf_amd.reparameterize_ray(shape, ray_o, num_rays=4, kappa=1e5, exponent=3.0)
+        ((dd * gdir).sum() + (det * gdv).sum()).backward()
+    fn["reparam"] = _reparam
 for k in a.kinds:
     fn[k](); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -1,0 +1,100 @@
+"""Warped-area reparameterisation of rays for the heightfield (reparam.py:10-123, 151-333).
+CPU: the oracle restatement -- forward and backward mode are transposes of each other; the known answer
+the reference tests state for a moving shape (src/render/tests/test_reparameterization.py:29-98: the
+derivative of the direction equals the motion of the attached hit point) carried over to a rising
+height field.  GPU: hf_reparam_* + hf_ray_intersect + hf_adjoint (host mirror hf_amd.reparameterize_ray)
+against the oracle."""
+import numpy as np
+import pytest
+
+
+def _scene(oracle, W=33, H=29, seed=0):
+    rng = np.random.default_rng(seed)
+    u = np.arange(W) / (W - 1.0); v = np.arange(H)[:, None] / (H - 1.0)
+    h = (0.5 + 0.3 * np.sin(2 * np.pi * 1.5 * u) * np.cos(2 * np.pi * 1.2 * v) + 0.03 * rng.uniform(-1, 1, (H, W))).astype(np.float32)
+    return h, oracle.OracleField(h, max_height=0.5)
+
+
+def _rays(n, rng):
+    tgt = np.stack([rng.uniform(-0.8, 0.8, n), rng.uniform(-0.8, 0.8, n), np.full(n, 0.25)])
+    o = tgt + np.stack([rng.uniform(-0.6, 0.6, n), rng.uniform(-0.6, 0.6, n), rng.uniform(1.0, 2.0, n)])
+    d = tgt - o; d /= np.linalg.norm(d, axis=0)
+    return o.astype(np.float32), d.astype(np.float32)
+
+
+@pytest.mark.parametrize("kappa,antithetic", [(30.0, False), (2000.0, True)])
+def test_oracle_backward_is_the_transpose_of_forward(oracle, kappa, antithetic):
+    h, f = _scene(oracle)
+    rng = np.random.default_rng(1)
+    o, d = _rays(40, rng)
+    dh = rng.normal(size=h.shape)
+    gd = rng.normal(size=(3, 40)); gdiv = rng.normal(size=40)
+    Vt, div = oracle.reparam_forward(f, o, d, dh, num_rays=6, kappa=kappa, antithetic=antithetic, seed=3)
+    gh = oracle.reparam_backward(f, o, d, gd, gdiv, num_rays=6, kappa=kappa, antithetic=antithetic, seed=3)
+    dd = d.astype(np.float64)
+    PV = Vt - dd * (dd * Vt).sum(0)                      # the backward differentiates normalize(d + V_theta)
+    lhs = (gd * PV).sum() + (gdiv * div).sum()
+    rhs = (gh * dh).sum()
+    assert np.isclose(lhs, rhs, rtol=2e-4, atol=1e-7), (lhs, rhs)
+    assert abs(rhs) > 1e-6
+
+
+def test_oracle_direction_follows_a_rising_surface(oracle):
+    """test_reparameterization.py:29-98 with 'the shape translates' -> 'all heights rise': for concentrated
+    auxiliary rays the derivative of the direction is the motion of the attached hit point, projected."""
+    h = np.full((17, 17), 0.5, np.float32)                # flat, hit far from the border
+    f = oracle.OracleField(h, max_height=0.5)
+    o = np.array([[0.1], [-0.05], [2.0]], np.float32); d = np.array([[0.2], [0.1], [-1.0]], np.float32); d /= np.linalg.norm(d)
+    Vt, div = oracle.reparam_forward(f, o, d, np.ones_like(h, dtype=np.float64), num_rays=32, kappa=1e6, exponent=3.0)
+    r = np.concatenate([o, d, [[np.inf]]]).astype(np.float32)
+    t, u, v, prim = f.ray_intersect_preliminary(r)
+    p = f.compute_surface_interaction(r, t, u, v, prim, oracle.RAY_ALL)["p"].astype(np.float64)
+    eps = 1e-4
+    new_d = (p + np.array([[0], [0], [0.5 * eps]]) - o); new_d /= np.linalg.norm(new_d)
+    fd = (new_d - d.astype(np.float64)) / eps
+    assert np.allclose(Vt, fd, atol=1e-2 * np.abs(fd).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kappa,antithetic,num_rays", [(30.0, False, 5), (2000.0, True, 8), (1e5, False, 4)])
+def test_gpu_reparameterize_ray_matches_oracle(hf, oracle, kappa, antithetic, num_rays):
+    import torch
+    h, f = _scene(oracle, seed=2)
+    rng = np.random.default_rng(4)
+    n = 3000
+    o, d = _rays(n, rng)
+    active = (rng.uniform(size=n) < 0.9)
+    shape = hf.Heightfield(heightfield=torch.from_numpy(h).cuda(), max_height=0.5)
+    shape.heightfield.requires_grad_(True)
+    ray = hf.Ray3f(torch.from_numpy(o).cuda(), torch.from_numpy(d).cuda())
+    dirn, det = hf.reparameterize_ray(shape, ray, num_rays=num_rays, kappa=kappa, exponent=3.0, antithetic=antithetic,
+                                      seed=7, active=torch.from_numpy(active).cuda())
+    assert torch.equal(dirn, ray.d) and bool((det == 1).all())                  # identity in primal mode
+    gd = rng.normal(size=(3, n)).astype(np.float32); gdiv = rng.normal(size=n).astype(np.float32)
+    ((dirn * torch.from_numpy(gd).cuda()).sum() + (det * torch.from_numpy(gdiv).cuda()).sum()).backward()
+    got = shape.heightfield.grad.cpu().numpy().astype(np.float64)
+    ref = oracle.reparam_backward(f, o, d, gd, gdiv, num_rays=num_rays, kappa=kappa, exponent=3.0, antithetic=antithetic,
+                                  seed=7, active=active)
+    assert np.linalg.norm(ref) > 0
+    rel = np.linalg.norm(got - ref) / np.linalg.norm(ref)
+    assert rel <= 3e-5, rel   # measured 1e-6 .. 9e-6: the weights are (1/(D-1+B))^3, float32 like the reference's Float
+
+
+@pytest.mark.gpu
+def test_gpu_aux_rays_match_oracle(hf, oracle):
+    import ctypes as C
+    import torch
+    from hf_amd import _capi
+    rng = np.random.default_rng(9)
+    n = 5000
+    o, d = _rays(n, rng)
+    ot, dt = torch.from_numpy(o).cuda(), torch.from_numpy(d).cuda()
+    ad = torch.empty_like(dt); mt = torch.empty(n, device="cuda")
+    p3 = lambda x: (C.c_void_p * 3)(x[0].data_ptr(), x[1].data_ptr(), x[2].data_ptr())
+    for k, kappa, anti in [(0, 30.0, False), (3, 500.0, True), (2, 1e5, True)]:
+        _capi.check(_capi.lib().hf_reparam_aux_rays(n, C.byref(p3(ot)), C.byref(p3(dt)), None, k, kappa, int(anti), 11,
+                                                    C.byref(p3(ad)), mt.data_ptr(), None))
+        ref = oracle.reparam_aux_rays(o, d, k, kappa, anti, 11)
+        got = ad.cpu().numpy()
+        assert np.allclose(got, ref[3:6], atol=2e-6), np.abs(got - ref[3:6]).max()
+        assert np.allclose(np.linalg.norm(got, axis=0), 1.0, atol=1e-5) and bool(torch.isinf(mt).all())
