@@ -67,7 +67,7 @@ __global__ __launch_bounds__(HF_BLOCK) void hf_mip_reduce_kernel(const float2 *_
     out[idx] = make_float2(fminf(fminf(a.x, b.x), fminf(d.x, e.x)), fmaxf(fmaxf(a.y, b.y), fmaxf(d.y, e.y)));
 }
 
-// sheared bounds of level L (see hf_device.h): one thread per (node, child)
+// sheared bounds of level L (see hf_device.h): one thread per (node, child), then one per node
 __global__ __launch_bounds__(HF_BLOCK) void hf_shear_kernel(const float *__restrict__ h, int W, int H, float s, int L,
                                                            int sh, float4 *__restrict__ out) {
     const int idx = blockIdx.x * HF_BLOCK + threadIdx.x;
@@ -99,16 +99,30 @@ __global__ __launch_bounds__(HF_BLOCK) void hf_shear_kernel(const float *__restr
         lo -= eps; hi += eps;
     }
     float *rec = (float *) (out + (size_t) node * 3);
-    if (j == 0) { rec[0] = a; rec[1] = b; rec[2] = c; rec[3] = __builtin_fabsf(a) + __builtin_fabsf(b); }
+    if (j == 0) { rec[0] = a; rec[1] = b; rec[2] = c; }
     rec[4 + 2 * j] = lo; rec[5 + 2 * j] = hi;
+}
+// Fourth entry of the record: what the walk multiplies its xy uncertainty m by to get a z uncertainty -- the slope
+// of the plane, |a|+|b| per cell, PLUS the largest sheared range of a child: the triangle test may report a hit up
+// to m cells beside the walk's ray (that is what m stands for), and where the surface is far steeper than the plane
+// (a needle triangle) those m cells are up to m x range up or down.
+__global__ __launch_bounds__(HF_BLOCK) void hf_shear_slope_kernel(int sh, float4 *__restrict__ out) {
+    const int node = blockIdx.x * HF_BLOCK + threadIdx.x;
+    if (node >= (1 << (2 * sh))) return;
+    float4 *rec = out + (size_t) node * 3;
+    const float4 pl = rec[0], q01 = rec[1], q23 = rec[2];
+    const float rmax = fmaxf(fmaxf(fmaxf(q01.y - q01.x, q01.w - q01.z), fmaxf(q23.y - q23.x, q23.w - q23.z)), 0.f); // absent: -inf
+    rec[0].w = __builtin_fabsf(pl.x) + __builtin_fabsf(pl.y) + rmax;
 }
 
 void hf_launch_build_mips(const hf_dev_field &f, float2 *mip, float4 *shear, hipStream_t stream) {
     const int top = f.top;
     for (int L = 2; L <= top && L <= HF_SHEAR_TOP; ++L) {
-        const int k = top - L, n = 4 << (2 * k), grid = (n + HF_BLOCK - 1) / HF_BLOCK;
-        hipLaunchKernelGGL(hf_shear_kernel, dim3(grid), dim3(HF_BLOCK), 0, stream, f.h, f.W, f.H, f.s, L, k,
-                           shear + (size_t) (hf_depth_off(k) - 1u) * 3);
+        const int k = top - L, n = 1 << (2 * k);
+        float4 *recs = shear + (size_t) (hf_depth_off(k) - 1u) * 3;
+        hipLaunchKernelGGL(hf_shear_kernel, dim3((4 * n + HF_BLOCK - 1) / HF_BLOCK), dim3(HF_BLOCK), 0, stream, f.h, f.W,
+                           f.H, f.s, L, k, recs);
+        hipLaunchKernelGGL(hf_shear_slope_kernel, dim3((n + HF_BLOCK - 1) / HF_BLOCK), dim3(HF_BLOCK), 0, stream, k, recs);
     }
     (void) hipMemsetAsync(mip, 0, sizeof(float2), stream); // padding entry
     for (int k = top - 1; k >= 0; --k) {
@@ -320,6 +334,10 @@ __device__ __forceinline__ uint32_t block_cells(const hf_dev_field &f, const hf_
     float gz, dz, mz;
     shear_line(f, rs, fx, fy, a, b, c, __builtin_fabsf(a) + __builtin_fabsf(b), fX + 1.f, fY + 1.f, gz, dz, mz);
     mz += 1e-6f * (__builtin_fabsf(c) + __builtin_fabsf(a) + __builtin_fabsf(b)); // rounding of the w's
+    {   // needle triangles (see walk_subtree): m cells beside the ray are up to m x (range of the cell) above / below it
+        const float rmax = fmaxf(fmaxf(q.hi[0] - q.lo[0], q.hi[1] - q.lo[1]), fmaxf(q.hi[2] - q.lo[2], q.hi[3] - q.lo[3]));
+        mz = __builtin_fmaf(0.5f * (r.gxm - r.gxp), rmax, mz);
+    }
     return child_mask(r, fx, fy, fX, fY, 1.f, q, gz, dz, mz, thi);
 }
 

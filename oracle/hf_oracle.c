@@ -389,7 +389,10 @@ static void trace_hier(const hfo_field *f, const float o[3], const float d[3], f
             }
             if (inside) {
                 float z0 = fmaf(t0, dz, gz), z1 = fmaf(t1, dz, gz);
-                float rlo = fminf(z0, z1) - mz, rhi = fmaxf(z0, z1) + mz;
+                /* the triangle test may report a hit up to m cells beside the walk's ray; on a needle
+                 * triangle that is up to m x (height range of the cell) above or below it */
+                const float mzz = fmaf(m, zhi - zlo, mz);
+                float rlo = fminf(z0, z1) - mzz, rhi = fmaxf(z0, z1) + mzz;
                 overlap = rlo <= zhi && rhi >= zlo;
             }
         }

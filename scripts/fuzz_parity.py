@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Randomised parity search (tool, not a test): random grids / transforms / ray mixes, every ray's prim_index,
+t and any-hit mask compared bit for bit with the oracle.  usage: fuzz_parity.py [scenes] [rays] [seed]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch
+import hf_amd, common
+from oracle import hf_oracle as O
+
+scenes, nrays, seed0 = (int(sys.argv[k]) if len(sys.argv) > k else v for k, v in ((1, 100), (2, 60000), (3, 0)))
+O.build()
+bad_total, t0 = 0, time.time()
+for sc in range(scenes):
+    rng = np.random.default_rng(seed0 * 100003 + sc)
+    W, H = (int(np.exp(rng.uniform(np.log(2), np.log(float(os.environ.get("FUZZ_MAXDIM", "700")))))) for _ in range(2))
+    kind = rng.choice(["rand", "sine", "stairs", "flat", "steep", "ridge"])
+    u = np.arange(W) / max(W - 1.0, 1); v = np.arange(H)[:, None] / max(H - 1.0, 1)
+    if kind == "steep":
+        h = (0.5 + 0.45 * np.sin(2 * np.pi * rng.uniform(1, 20) * u) * np.cos(2 * np.pi * rng.uniform(1, 20) * v)).astype(np.float32)
+    elif kind == "ridge":
+        h = (0.2 + 0.6 * np.abs(((u * rng.integers(1, 9)) % 1.0) - 0.5) + 0.2 * v).astype(np.float32)
+    else:
+        h = common.heights(kind, W, H, rng)
+    mh = float(np.exp(rng.uniform(np.log(1e-3), np.log(10.0))))
+    tw = common.affine(int(rng.integers(1 << 30))) if rng.uniform() < 0.5 else None
+    f_o = O.OracleField(h, max_height=mh, to_world=tw)
+    props = dict(heightfield=torch.from_numpy(h), max_height=mh)
+    if tw is not None:
+        props["to_world"] = torch.from_numpy(tw)
+    f_g = hf_amd.Heightfield(props)
+    n1 = nrays // 3
+    parts = [common.random_rays(n1, rng, mh), common.inside_rays(n1, rng, mh)]
+    # coherent packets, some from far away, some grazing
+    npix = max(1, (nrays - 2 * n1) // 64)
+    c = rng.uniform(-1.1, 1.1, (2, npix)); dirs = rng.normal(size=(3, npix)); dirs[2] = -np.abs(dirs[2]) * rng.uniform(0.02, 1.0)
+    dirs /= np.linalg.norm(dirs, axis=0)
+    dist = np.exp(rng.uniform(np.log(0.5), np.log(50.0)))
+    o = np.concatenate([c, np.full((1, npix), mh * 0.5)]) - dirs * dist
+    o = np.repeat(o, 64, 1) + rng.uniform(-1, 1, (3, npix * 64)) * np.exp(rng.uniform(np.log(1e-4), np.log(3e-2)))
+    d = np.repeat(dirs, 64, 1) * (1 + rng.uniform(-1e-3, 1e-3, (1, npix * 64)))
+    pk = np.concatenate([o, d, np.full((1, npix * 64), np.inf)]).astype(np.float32)
+    r = common.to_world_rays(np.concatenate([pk] + parts, 1), tw)
+    rt = torch.from_numpy(r).cuda()
+    ray = hf_amd.Ray3f(rt[0:3].contiguous(), rt[3:6].contiguous(), rt[6].contiguous())
+    pi = f_g.ray_intersect_preliminary(ray)
+    t, uu, vv, prim = f_o.ray_intersect_preliminary(r, nthreads=16)
+    pg, tg = pi.prim_index.cpu().numpy().view(np.uint32), pi.t.cpu().numpy()
+    bad = np.nonzero((prim != pg) | (t != tg))[0]
+    st = f_g.ray_test(ray).cpu().numpy()
+    bad2 = np.nonzero(st != np.isfinite(t))[0]
+    if bad.size or bad2.size:
+        bad_total += bad.size + bad2.size
+        print(f"scene {sc} ({W}x{H} {kind} mh={mh:.3g} tw={'y' if tw is not None else 'n'}): {bad.size} closest-hit, {bad2.size} any-hit mismatches; first ray {r[:, (bad if bad.size else bad2)[0]].tolist()}", flush=True)
+    if sc % 20 == 0:
+        print(f"scene {sc}: {W}x{H} {kind}, hit fraction {np.isfinite(t).mean():.2f}, {time.time() - t0:.0f} s", flush=True)
+print(f"{scenes} scenes x {r.shape[1]} rays: {bad_total} mismatches")
+sys.exit(1 if bad_total else 0)
