@@ -52,6 +52,30 @@ for sc in range(scenes):
     if bad.size or bad2.size:
         bad_total += bad.size + bad2.size
         print(f"scene {sc} ({W}x{H} {kind} mh={mh:.3g} tw={'y' if tw is not None else 'n'}): {bad.size} closest-hit, {bad2.size} any-hit mismatches; first ray {r[:, (bad if bad.size else bad2)[0]].tolist()}", flush=True)
+    if os.environ.get("FUZZ_SI") and sc % 5 == 0:
+        # surface interaction + adjoint on a slice of the rays (floating point: 1e-5 relative)
+        k = min(20000, r.shape[1]); rs = np.ascontiguousarray(r[:, :k])
+        f_g.heightfield.requires_grad_(True)
+        rt2 = torch.from_numpy(rs).cuda()
+        si = f_g.ray_intersect(hf_amd.Ray3f(rt2[0:3].contiguous(), rt2[3:6].contiguous(), rt2[6].contiguous()), hf_amd.RayFlags.All)
+        rec = f_o.compute_surface_interaction(rs, t[:k], uu[:k], vv[:k], prim[:k], O.RAY_ALL, nthreads=16)
+        hit = np.isfinite(t[:k])
+        for name, got in (("p", si.p), ("n", si.n), ("uv", si.uv), ("dp_du", si.dp_du), ("dp_dv", si.dp_dv)):
+            a, b = got.detach().cpu().numpy()[:, hit], rec[name][:, hit]
+            scale = max(1.0, float(np.abs(b).max())) if b.size else 1.0
+            if b.size and not np.allclose(a, b, rtol=1e-5, atol=1e-5 * scale):
+                bad_total += 1
+                print(f"scene {sc}: SI field {name} differs, max abs {np.abs(a - b).max():.3g} (scale {scale:.3g})", flush=True)
+        gt = rng.normal(size=k).astype(np.float32); gp = rng.normal(size=(3, k)).astype(np.float32); gn = rng.normal(size=(3, k)).astype(np.float32)
+        valid = si.is_valid()
+        loss = (torch.where(valid, si.t, torch.zeros_like(si.t)) * torch.from_numpy(gt).cuda()).sum() + (si.p * torch.from_numpy(gp).cuda()).sum() + (si.n * torch.from_numpy(gn).cuda()).sum()
+        loss.backward()
+        gh = f_o.adjoint(rs, t[:k], uu[:k], vv[:k], prim[:k], {"t": (gt * hit)[None], "p": gp, "n": gn}, O.RAY_ALL, nthreads=16)
+        got = f_g.heightfield.grad.cpu().numpy()
+        err = np.linalg.norm(got - gh) / max(np.linalg.norm(gh), 1e-30)
+        if not err <= 1e-4:
+            bad_total += 1
+            print(f"scene {sc}: height gradient rel L2 err {err:.3g} (|g| {np.linalg.norm(gh):.3g})", flush=True)
     if sc % 20 == 0:
         print(f"scene {sc}: {W}x{H} {kind}, hit fraction {np.isfinite(t).mean():.2f}, {time.time() - t0:.0f} s", flush=True)
 print(f"{scenes} scenes x {r.shape[1]} rays: {bad_total} mismatches")
