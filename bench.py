@@ -165,7 +165,7 @@ def main():
                     "fwd_ms": round(fwd_ms, 4), "adj_ms": round(adj_ms, 4),
                     "fwd_adj_frac": round(((fwd_bytes + adj_bytes) / ((fwd_ms + adj_ms) * 1e-3) / 1e9) / HBM_PEAK_GBS, 5)}
         extras = None
-        if world == 1:
+        if world == 1 and os.environ.get("HF_BENCH_EXTRAS", "1") != "0":  # profile_round.sh switches them off
             extras = other_launches(torch, hf_amd, _capi, lib, shape, r_s, pi_s, si_s, si, R, stream, flags)
         cpu = None
         if world == 1 and args.cpu_seconds > 0:

@@ -1,0 +1,25 @@
+#!/bin/bash
+# usage (on the GPU box, via gpurun): scripts/profile_round.sh TAG
+# rocprofv3 kernel stats of the bench command + PMC traffic / instruction counters of the kernels, reduced to
+# small CSV files under gpurun_out/TAG/ (the rocpd databases are deleted: gpurun copies back at most 64 MiB).
+set -e
+TAG=${1:-prof}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$R/gpurun_out/$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+# (the other-launch timings are switched off here so that every launch of a kernel in the table is the bench workload)
+HF_BENCH_EXTRAS=0 rocprofv3 --kernel-trace --stats -d $OUT/stats -o run -- python $R/bench.py --steps 5 --warmup 2 > $OUT/bench_under_rocprof.log 2>&1
+python $R/scripts/rocpd_summary.py stats_ms $OUT/stats/run_results.db > $OUT/kernel_stats.csv
+grep '^{"metric"' $OUT/bench_under_rocprof.log > $OUT/bench.json
+rm -rf $OUT/stats
+for C in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --kernel-trace --pmc $C -d $OUT/pmc_$C -o run -- python $R/scripts/prof_kernels.py --iters 1 fwd adj miss > $OUT/pmc_$C.log 2>&1
+  python $R/scripts/rocpd_summary.py pmc $OUT/pmc_$C/run_results.db hf_ > $OUT/pmc_$C.csv
+  rm -rf $OUT/pmc_$C
+done
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES -d $OUT/pmc_sq -o run -- python $R/scripts/prof_kernels.py --iters 1 fwd miss > $OUT/pmc_sq.log 2>&1
+python $R/scripts/rocpd_summary.py pmc $OUT/pmc_sq/run_results.db hf_trace > $OUT/pmc_sq.csv
+rm -rf $OUT/pmc_sq
+cd $R && python bench.py --steps 20 --warmup 3 > $OUT/bench_20steps.json
+ls -la $OUT
