@@ -177,6 +177,8 @@ int hf_heights_device(hf_field_t *hf, const float **out);
 int hf_dims(const hf_field_t *hf, uint32_t *width, uint32_t *height);
 
 /* ---- the hot path ------------------------------------------------------------ */
+/* All of these launch on `stream` and return immediately; the calling thread's current HIP device must be the
+ * handle's (HF_EDEVICE otherwise), all arrays are device memory of that device. */
 
 /* Replaces: Shape::ray_intersect_preliminary(const Ray3f&, Mask)
  * (include/mitsuba/render/shape.h:137-138, wrapper shape.h:621-629; called from

@@ -271,6 +271,11 @@ static int check_rays(const char *fn, const hf_field_t *hf, size_t n, const hf_r
     for (int k = 0; k < 3; ++k)
         if (!rays->o[k] || !rays->d[k]) return fail(HF_EINVAL, "%s: NULL ray component array", fn);
     if (!rays->maxt) return fail(HF_EINVAL, "%s: NULL ray maxt array", fn);
+    // the launch goes to the calling thread's current device: it must be the handle's (the query functions do
+    // not switch devices behind the caller's back)
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != hf->device)
+        return fail(HF_EDEVICE, "%s: current HIP device is %d, the heightfield lives on device %d", fn, cur, hf->device);
     return HF_OK;
 }
 
