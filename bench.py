@@ -56,11 +56,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
+    # HF_BENCH_BACKEND=gloo rehearses the multi-rank path on fewer GPUs than ranks (ranks share devices; the
+    # all-reduce then goes through the host).  The measured configuration is nccl = RCCL, one rank per GPU.
+    backend = os.environ.get("HF_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     N, Wf, spp = args.grid, args.film, args.spp
