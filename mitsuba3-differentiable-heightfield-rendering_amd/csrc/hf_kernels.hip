@@ -1078,6 +1078,7 @@ void hf_launch_adam(size_t n, float *h, const float *g, float *m, float *v, floa
 // Minimal direct lighting on the wavefront (include/hf.h): one lane per sample, coalesced SoA loads,
 // the box-filter film as a shuffle tree over the samples of a pixel.  Pure streaming: 28 B/sample in.
 // ---------------------------------------------------------------------------------
+#define HF_DPP_ADD(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xF, 0xF, false))
 struct hf_f3ptr { const float *p[3]; };
 struct hf_f3out { float *p[3]; };
 
@@ -1098,7 +1099,13 @@ __global__ __launch_bounds__(HF_BLOCK) void hf_direct_kernel(size_t n, uint32_t 
         const float co = dot3(nn, mk3(L.l[k][0], L.l[k][1], L.l[k][2]));
         float c = (lit && co > 0.f && (L.vis[k] ? L.vis[k][ii] != 0 : true)) ? L.w[k] * co : 0.f;
         if (pow2) {
-            for (uint32_t off = 1; off < g; off <<= 1) c += __shfl_xor(c, (int) off);
+            // butterfly over the g = min(spp, 64) lanes of a pixel: DPP within rows of 16, cross-lane beyond
+            if (g > 1u) c += HF_DPP_ADD(c, 0xB1);   // quad_perm [1,0,3,2]
+            if (g > 2u) c += HF_DPP_ADD(c, 0x4E);   // quad_perm [2,3,0,1]
+            if (g > 4u) c += HF_DPP_ADD(c, 0x141);  // row_half_mirror: the other quad pair
+            if (g > 8u) c += HF_DPP_ADD(c, 0x140);  // row_mirror: the other half row
+            if (g > 16u) c += __shfl_xor(c, 16);
+            if (g > 32u) c += __shfl_xor(c, 32);
             if (in && (threadIdx.x & (g - 1u)) == 0u) {
                 if (spp <= 64u) image[k * npix + i / spp] = c * inv_spp;          // the wave holds whole pixels
                 else            atomicAdd(&image[k * npix + i / spp], c * inv_spp); // several waves per pixel
