@@ -2,7 +2,7 @@
 """Largest grids (tool): N x N heights up to the 2^30-vertex limit, 200 k mixed rays against the oracle.
 usage: big_grid_check.py N"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import hf_amd, common

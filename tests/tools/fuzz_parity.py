@@ -2,7 +2,7 @@
 """Randomised parity search (tool, not a test): random grids / transforms / ray mixes, every ray's prim_index,
 t and any-hit mask compared bit for bit with the oracle.  usage: fuzz_parity.py [scenes] [rays] [seed]"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import hf_amd, common
