@@ -57,9 +57,17 @@ for sc in range(scenes):
         k = min(20000, r.shape[1]); rs = np.ascontiguousarray(r[:, :k])
         f_g.heightfield.requires_grad_(True)
         rt2 = torch.from_numpy(rs).cuda()
-        si = f_g.ray_intersect(hf_amd.Ray3f(rt2[0:3].contiguous(), rt2[3:6].contiguous(), rt2[6].contiguous()), hf_amd.RayFlags.All)
-        rec = f_o.compute_surface_interaction(rs, t[:k], uu[:k], vv[:k], prim[:k], O.RAY_ALL, nthreads=16)
-        hit = np.isfinite(t[:k])
+        # random differentiation mode / boundary test (interaction.h:19-69); a random active mask
+        fl = O.RAY_ALL | int(rng.choice([0, 0x80, 0x100])) | int(rng.choice([0, 0x40]))
+        act = rng.uniform(size=k) < 0.9
+        si = f_g.ray_intersect(hf_amd.Ray3f(rt2[0:3].contiguous(), rt2[3:6].contiguous(), rt2[6].contiguous()), fl,
+                               active=torch.from_numpy(act).cuda())
+        t_a = np.where(act, t[:k], np.inf).astype(np.float32)
+        rec = f_o.compute_surface_interaction(rs, t_a, uu[:k], vv[:k], prim[:k], fl, active=act, nthreads=16)
+        if (fl & 0x40) and not np.allclose(si.boundary_test.detach().cpu().numpy(), rec["boundary_test"], rtol=1e-4, atol=1e-5):
+            bad_total += 1
+            print(f"scene {sc}: boundary_test differs", flush=True)
+        hit = np.isfinite(t_a)
         for name, got in (("p", si.p), ("n", si.n), ("uv", si.uv), ("dp_du", si.dp_du), ("dp_dv", si.dp_dv)):
             a, b = got.detach().cpu().numpy()[:, hit], rec[name][:, hit]
             scale = max(1.0, float(np.abs(b).max())) if b.size else 1.0
@@ -69,10 +77,12 @@ for sc in range(scenes):
         gt = rng.normal(size=k).astype(np.float32); gp = rng.normal(size=(3, k)).astype(np.float32); gn = rng.normal(size=(3, k)).astype(np.float32)
         valid = si.is_valid()
         loss = (torch.where(valid, si.t, torch.zeros_like(si.t)) * torch.from_numpy(gt).cuda()).sum() + (si.p * torch.from_numpy(gp).cuda()).sum() + (si.n * torch.from_numpy(gn).cuda()).sum()
-        loss.backward()
-        gh = f_o.adjoint(rs, t[:k], uu[:k], vv[:k], prim[:k], {"t": (gt * hit)[None], "p": gp, "n": gn}, O.RAY_ALL, nthreads=16)
-        got = f_g.heightfield.grad.cpu().numpy()
-        err = np.linalg.norm(got - gh) / max(np.linalg.norm(gh), 1e-30)
+        f_g.heightfield.grad = None
+        if loss.requires_grad:          # DetachShape: no path to the heights (mesh.cpp:713-717)
+            loss.backward()
+        gh = f_o.adjoint(rs, t_a, uu[:k], vv[:k], prim[:k], {"t": (gt * hit)[None], "p": gp, "n": gn}, fl, active=act, nthreads=16)
+        got = f_g.heightfield.grad.cpu().numpy() if f_g.heightfield.grad is not None else np.zeros_like(gh)
+        err = np.linalg.norm(got - gh) / max(np.linalg.norm(gh), 1e-30) if np.linalg.norm(gh) > 0 else float(np.abs(got).max())
         if not err <= 1e-4:
             bad_total += 1
             print(f"scene {sc}: height gradient rel L2 err {err:.3g} (|g| {np.linalg.norm(gh):.3g})", flush=True)
