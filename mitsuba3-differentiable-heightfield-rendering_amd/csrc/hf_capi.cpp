@@ -4,11 +4,13 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
-#include <atomic>
+#include <mutex>
+#include <new>
 #include <vector>
 
 #include "hf_launch.h"
 
+#define HF_NUM_COUNTERS 256
 struct hf_field {
     hf_dev_field dev;   // device view handed to kernels by value
     float *d_heights;   // owned copy of the heights
@@ -17,14 +19,46 @@ struct hf_field {
     size_t mip_nodes;
     int device;
     hipEvent_t built;   // completion of the last hf_set_heights*
-    unsigned long long *d_counters; // ring of work counters, one per in-flight trace launch
-    std::atomic<uint32_t> next_counter;
+    // Ring of work counters, one slot per in-flight trace launch.  Every slot carries the completion event of
+    // the launch that used it last: a launch that re-uses the slot first makes its stream wait for that event
+    // (a device-side wait, normally long past), so two pending launches never share or reset a counter, and
+    // hf_destroy waits for exactly the launches of this handle instead of the whole device.
+    unsigned long long *d_counters;
+    hipEvent_t slot_done[HF_NUM_COUNTERS];
+    bool slot_used[HF_NUM_COUNTERS];
+    uint32_t next_slot;
+    std::mutex *slot_mutex;
 };
 
-#define HF_NUM_COUNTERS 1024
-static unsigned long long *next_counter(const hf_field *hf) {
+// keeps the caller's current device across a call that has to work on the handle's device
+struct hf_device_guard {
+    int prev = -1;
+    bool ok = true;
+    explicit hf_device_guard(int dev) {
+        int cur = -1;
+        if (hipGetDevice(&cur) != hipSuccess) cur = -1;
+        if (cur != dev) {
+            ok = hipSetDevice(dev) == hipSuccess;
+            prev = cur;
+        }
+    }
+    ~hf_device_guard() { if (prev >= 0) (void) hipSetDevice(prev); }
+};
+
+// claims the next counter slot for a launch on `stream`; *slot receives the slot number for slot_release
+static unsigned long long *slot_acquire(const hf_field *hf, hipStream_t stream, uint32_t *slot) {
     hf_field *m = const_cast<hf_field *>(hf);
-    return m->d_counters + (m->next_counter.fetch_add(1) % HF_NUM_COUNTERS) * 16; // 128-byte apart
+    std::lock_guard<std::mutex> lock(*m->slot_mutex);
+    const uint32_t k = m->next_slot++ % HF_NUM_COUNTERS;
+    if (m->slot_used[k]) (void) hipStreamWaitEvent(stream, m->slot_done[k], 0);
+    *slot = k;
+    return m->d_counters + (size_t) k * 16; // 128 bytes apart
+}
+static void slot_release(const hf_field *hf, hipStream_t stream, uint32_t slot) {
+    hf_field *m = const_cast<hf_field *>(hf);
+    std::lock_guard<std::mutex> lock(*m->slot_mutex);
+    (void) hipEventRecord(m->slot_done[slot], stream);
+    m->slot_used[slot] = true;
 }
 
 static thread_local char g_err[512] = "no error";
@@ -86,6 +120,19 @@ static int set_transform(hf_field *hf, const float *to_world, const float *to_ob
     return hf_invert_affine(to_world, hf->dev.to_object);
 }
 
+// frees whatever a (possibly half-constructed) handle owns
+static void release(hf_field *hf) {
+    if (hf->built) (void) hipEventDestroy(hf->built);
+    for (int k = 0; k < HF_NUM_COUNTERS; ++k)
+        if (hf->slot_done[k]) (void) hipEventDestroy(hf->slot_done[k]);
+    if (hf->d_heights) (void) hipFree(hf->d_heights);
+    if (hf->d_mip) (void) hipFree(hf->d_mip);
+    if (hf->d_shear) (void) hipFree(hf->d_shear);
+    if (hf->d_counters) (void) hipFree(hf->d_counters);
+    delete hf->slot_mutex;
+    free(hf);
+}
+
 extern "C" int hf_create(const hf_desc_t *desc, hf_field_t **out) {
     if (!desc || !out) return fail(HF_EINVAL, "hf_create: NULL argument");
     *out = nullptr;
@@ -98,9 +145,10 @@ extern "C" int hf_create(const hf_desc_t *desc, hf_field_t **out) {
     HF_HIP(hipGetDeviceCount(&ndev));
     if (desc->device < 0 || desc->device >= ndev)
         return fail(HF_EDEVICE, "hf_create: device %d not available (%d devices)", desc->device, ndev);
-    HF_HIP(hipSetDevice(desc->device));
+    hf_device_guard guard(desc->device); // the caller's current device is restored on return
+    if (!guard.ok) return fail(HF_EDEVICE, "hf_create: cannot select device %d", desc->device);
 
-    hf_field *hf = (hf_field *) calloc(1, sizeof(hf_field)); // zero-initialised POD + atomic
+    hf_field *hf = (hf_field *) calloc(1, sizeof(hf_field)); // zero-initialised POD
     if (!hf) return fail(HF_ENOMEM, "hf_create: host allocation failed");
     hf->device = desc->device;
     hf_dev_field &d = hf->dev;
@@ -129,41 +177,45 @@ extern "C" int hf_create(const hf_desc_t *desc, hf_field_t **out) {
     if (e == hipSuccess) e = hipMalloc((void **) &hf->d_shear, sizeof(float4) * 3 * (hf_shear_records(top) + 1));
     if (e == hipSuccess) e = hipMalloc((void **) &hf->d_counters, sizeof(unsigned long long) * 16 * HF_NUM_COUNTERS);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&hf->built, hipEventDisableTiming);
-    if (e != hipSuccess) {
-        if (hf->d_heights) (void) hipFree(hf->d_heights);
-        if (hf->d_mip) (void) hipFree(hf->d_mip);
-        if (hf->d_shear) (void) hipFree(hf->d_shear);
-        if (hf->d_counters) (void) hipFree(hf->d_counters);
-        free(hf);
-        return fail(e == hipErrorOutOfMemory ? HF_ENOMEM : HF_EDEVICE, "hf_create: %s", hipGetErrorString(e));
-    }
+    for (int k = 0; k < HF_NUM_COUNTERS && e == hipSuccess; ++k)
+        e = hipEventCreateWithFlags(&hf->slot_done[k], hipEventDisableTiming);
+    hf->slot_mutex = new (std::nothrow) std::mutex();
+    if (e == hipSuccess && !hf->slot_mutex) e = hipErrorOutOfMemory;
     d.h = hf->d_heights;
     d.mip = hf->d_mip;
     d.shear = hf->d_shear;
     // heights start as zero; build the pyramid so the handle is always traceable
-    HF_HIP(hipMemsetAsync(hf->d_heights, 0, sizeof(float) * (size_t) d.W * d.H, nullptr));
-    hf_launch_build_mips(d, hf->d_mip, hf->d_shear, nullptr);
-    HF_HIP(hipEventRecord(hf->built, nullptr));
-    HF_HIP(hipStreamSynchronize(nullptr));
+    if (e == hipSuccess) e = hipMemsetAsync(hf->d_heights, 0, sizeof(float) * (size_t) d.W * d.H, nullptr);
+    if (e == hipSuccess) {
+        hf_launch_build_mips(d, hf->d_mip, hf->d_shear, nullptr);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipEventRecord(hf->built, nullptr);
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+    if (e != hipSuccess) { // one exit for every failure after the first allocation: nothing leaks
+        release(hf);
+        return fail(e == hipErrorOutOfMemory ? HF_ENOMEM : HF_EDEVICE, "hf_create: %s", hipGetErrorString(e));
+    }
     *out = hf;
     return HF_OK;
 }
 
 extern "C" int hf_destroy(hf_field_t *hf) {
     if (!hf) return HF_OK;
-    (void) hipSetDevice(hf->device);
-    (void) hipDeviceSynchronize();
-    (void) hipEventDestroy(hf->built);
-    (void) hipFree(hf->d_heights);
-    (void) hipFree(hf->d_mip);
-    (void) hipFree(hf->d_shear);
-    (void) hipFree(hf->d_counters);
-    free(hf);
+    hf_device_guard guard(hf->device);
+    // wait for the work of THIS handle only (its last rebuild and the launches still holding a counter slot);
+    // other streams of the host application keep running
+    (void) hipEventSynchronize(hf->built);
+    for (int k = 0; k < HF_NUM_COUNTERS; ++k)
+        if (hf->slot_used[k]) (void) hipEventSynchronize(hf->slot_done[k]);
+    release(hf);
     return HF_OK;
 }
 
 extern "C" int hf_set_heights(hf_field_t *hf, const float *d_heights, hf_stream_t stream) {
     if (!hf || !d_heights) return fail(HF_EINVAL, "hf_set_heights: NULL argument");
+    hf_device_guard guard(hf->device);
+    if (!guard.ok) return fail(HF_EDEVICE, "hf_set_heights: cannot select device %d", hf->device);
     hipStream_t st = (hipStream_t) stream;
     const size_t bytes = sizeof(float) * (size_t) hf->dev.W * hf->dev.H;
     if (d_heights != hf->d_heights)
@@ -181,18 +233,21 @@ extern "C" int hf_adam_step(hf_field_t *hf, float *d_heights, const float *d_gra
     // optimizers.py:248-249
     if (!(beta1 >= 0. && beta1 < 1.) || !(beta2 >= 0. && beta2 < 1.) || !(lr > 0.) || !(eps > 0.) || step == 0)
         return fail(HF_EINVAL, "hf_adam_step: need 0 <= beta < 1, lr > 0, eps > 0, step >= 1");
-    HF_HIP(hipSetDevice(hf->device));
+    hf_device_guard guard(hf->device);
+    if (!guard.ok) return fail(HF_EDEVICE, "hf_adam_step: cannot select device %d", hf->device);
     // lr_scale in double, rounded once, like the Python scalar the reference makes opaque (optimizers.py:267-268)
     const float lr_scale = (float) (sqrt(1.0 - pow(beta2, (double) step)) / (1.0 - pow(beta1, (double) step)));
     const float lr_t = (float) lr * lr_scale;
     hf_launch_adam((size_t) hf->dev.W * hf->dev.H, d_heights, d_grad, d_m, d_v, lr_t, (float) beta1, (float) beta2,
-                   (float) eps, mask_updates, (hipStream_t) stream);
+                   (float) (1.0 - beta1), (float) (1.0 - beta2), (float) eps, mask_updates, (hipStream_t) stream);
     HF_HIP(hipGetLastError());
     return hf_set_heights(hf, d_heights, stream);
 }
 
 extern "C" int hf_set_heights_host(hf_field_t *hf, const float *h_heights, hf_stream_t stream) {
     if (!hf || !h_heights) return fail(HF_EINVAL, "hf_set_heights_host: NULL argument");
+    hf_device_guard guard(hf->device);
+    if (!guard.ok) return fail(HF_EDEVICE, "hf_set_heights_host: cannot select device %d", hf->device);
     hipStream_t st = (hipStream_t) stream;
     const size_t bytes = sizeof(float) * (size_t) hf->dev.W * hf->dev.H;
     HF_HIP(hipMemcpyAsync(hf->d_heights, h_heights, bytes, hipMemcpyHostToDevice, st));
@@ -227,6 +282,7 @@ extern "C" int hf_get_mip(const hf_field_t *hf, int level, float *h_out, uint32_
     if (w) *w = (uint32_t) wl;
     if (h) *h = (uint32_t) hl;
     if (h_out) { // existing nodes of the padded level, row-major (min,max) pairs
+        hf_device_guard guard(hf->device);
         std::vector<float> tmp(2 * ((size_t) 1 << (2 * k)));
         HF_HIP(hipEventSynchronize(hf->built));
         HF_HIP(hipMemcpy(tmp.data(), hf->d_mip + hf_depth_off(k), sizeof(float) * tmp.size(), hipMemcpyDeviceToHost));
@@ -244,6 +300,7 @@ extern "C" int hf_get_mip(const hf_field_t *hf, int level, float *h_out, uint32_
 extern "C" int hf_bbox(hf_field_t *hf, float out[6]) {
     if (!hf || !out) return fail(HF_EINVAL, "hf_bbox: NULL argument");
     float zr[2];
+    hf_device_guard guard(hf->device);
     HF_HIP(hipEventSynchronize(hf->built));
     HF_HIP(hipMemcpy(zr, hf->d_mip + 1, sizeof(zr), hipMemcpyDeviceToHost));
     const hf_dev_field &d = hf->dev;
@@ -297,7 +354,12 @@ extern "C" int hf_ray_intersect_preliminary(const hf_field_t *hf, size_t n, cons
     int rc = check_rays("hf_ray_intersect_preliminary", hf, n, rays);
     if (rc) return rc;
     if (!out || (n && !out->t)) return fail(HF_EINVAL, "hf_ray_intersect_preliminary: NULL output");
-    hf_launch_trace(0, hf->dev, n, rays, active, out, nullptr, nullptr, 0, next_counter(hf), (hipStream_t) stream);
+    {
+        uint32_t slot;
+        unsigned long long *counter = slot_acquire(hf, (hipStream_t) stream, &slot);
+        hf_launch_trace(0, hf->dev, n, rays, active, out, nullptr, nullptr, 0, counter, (hipStream_t) stream);
+        slot_release(hf, (hipStream_t) stream, slot);
+    }
     HF_HIP(hipGetLastError());
     return HF_OK;
 }
@@ -307,7 +369,12 @@ extern "C" int hf_ray_test(const hf_field_t *hf, size_t n, const hf_rays_t *rays
     int rc = check_rays("hf_ray_test", hf, n, rays);
     if (rc) return rc;
     if (n && !out_hit) return fail(HF_EINVAL, "hf_ray_test: NULL output");
-    hf_launch_trace(1, hf->dev, n, rays, active, nullptr, out_hit, nullptr, 0, next_counter(hf), (hipStream_t) stream);
+    {
+        uint32_t slot;
+        unsigned long long *counter = slot_acquire(hf, (hipStream_t) stream, &slot);
+        hf_launch_trace(1, hf->dev, n, rays, active, nullptr, out_hit, nullptr, 0, counter, (hipStream_t) stream);
+        slot_release(hf, (hipStream_t) stream, slot);
+    }
     HF_HIP(hipGetLastError());
     return HF_OK;
 }
@@ -332,8 +399,12 @@ extern "C" int hf_ray_intersect(const hf_field_t *hf, size_t n, const hf_rays_t 
     if (rc) return rc;
     if ((rc = check_flags("hf_ray_intersect", ray_flags))) return rc;
     if (!out_si) return fail(HF_EINVAL, "hf_ray_intersect: NULL output");
-    hf_launch_trace(2, hf->dev, n, rays, active, out_pi, nullptr, out_si, ray_flags, next_counter(hf),
-                    (hipStream_t) stream);
+    {
+        uint32_t slot;
+        unsigned long long *counter = slot_acquire(hf, (hipStream_t) stream, &slot);
+        hf_launch_trace(2, hf->dev, n, rays, active, out_pi, nullptr, out_si, ray_flags, counter, (hipStream_t) stream);
+        slot_release(hf, (hipStream_t) stream, slot);
+    }
     HF_HIP(hipGetLastError());
     return HF_OK;
 }

@@ -263,7 +263,9 @@ __device__ __forceinline__ bool setup_ray(const hf_dev_field &f, float2 zr, v3 o
     r.dz = od.z;
     if (fx) { gx = Wp - gx; dx = -dx; }
     if (fy) { gy = Wp - gy; dy = -dy; }
-    r.idx = 1.0f / dx; r.idy = 1.0f / dy; // +inf for axis-parallel rays
+    // |.|: a negative-zero component (d = -up, or a -0 surviving to_object) is mirrored by neither test above and
+    // would give -inf here, which flips every slab test below; canonicalised it is the +inf of an axis-parallel ray
+    r.idx = 1.0f / __builtin_fabsf(dx); r.idy = 1.0f / __builtin_fabsf(dy);
     const float reach = __builtin_fabsf(oo.x) + __builtin_fabsf(oo.y) +
                         tin * (__builtin_fabsf(od.x) + __builtin_fabsf(od.y)) + 2.f;
     // xy margin: covers the rounding of the walk and of the triangle test itself (which grows with
@@ -1054,9 +1056,9 @@ void hf_launch_adjoint(const hf_dev_field &f, size_t n, const hf_rays_t *rays, c
 // ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(HF_BLOCK) void hf_adam_kernel(size_t n, float *__restrict__ h, const float *__restrict__ g,
                                                           float *__restrict__ m, float *__restrict__ v, float lr_t,
-                                                          float beta1, float beta2, float eps, int mask_updates) {
+                                                          float beta1, float beta2, float c1, float c2, float eps,
+                                                          int mask_updates) {
     const size_t stride = (size_t) gridDim.x * HF_BLOCK;
-    const float c1 = 1.f - beta1, c2 = 1.f - beta2;
     for (size_t i = (size_t) blockIdx.x * HF_BLOCK + threadIdx.x; i < n; i += stride) {
         const float gi = g[i];
         if (mask_updates && gi == 0.f) continue;
@@ -1068,10 +1070,10 @@ __global__ __launch_bounds__(HF_BLOCK) void hf_adam_kernel(size_t n, float *__re
 }
 
 void hf_launch_adam(size_t n, float *h, const float *g, float *m, float *v, float lr_t, float beta1, float beta2,
-                    float eps, int mask_updates, hipStream_t stream) {
+                    float c1, float c2, float eps, int mask_updates, hipStream_t stream) {
     if (n == 0) return;
     hipLaunchKernelGGL(hf_adam_kernel, dim3(grid_for(n)), dim3(HF_BLOCK), 0, stream, n, h, g, m, v, lr_t, beta1, beta2,
-                       eps, mask_updates);
+                       c1, c2, eps, mask_updates);
 }
 
 // ---------------------------------------------------------------------------------

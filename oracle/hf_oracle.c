@@ -348,7 +348,8 @@ static void trace_hier(const hfo_field *f, const float o[3], const float d[3], f
     float dx = od[0] * hx, dy = od[1] * hy, dz = od[2];
     if (fx) { gx = Wp - gx; dx = -dx; }
     if (fy) { gy = Wp - gy; dy = -dy; }
-    const float idx = 1.0f / dx, idy = 1.0f / dy; /* +inf for axis-parallel rays */
+    /* |.|: a negative-zero component is not mirrored above and would give -inf; +inf for axis-parallel rays */
+    const float idx = 1.0f / fabsf(dx), idy = 1.0f / fabsf(dy);
     /* margins scale with the distance the ray travelled to reach the grid */
     const float reach = fabsf(oo[0]) + fabsf(oo[1]) + tin * (fabsf(od[0]) + fabsf(od[1])) + 2.f;
     const float m = 0.015625f + 4.8e-7f * reach * fmaxf(hx, hy);

@@ -242,7 +242,7 @@ def adam_step(h, g, m, v, lr, beta1=0.9, beta2=0.999, eps=1e-8, step=1, mask_upd
     lr_scale = f(np.sqrt(1.0 - float(beta2) ** int(step)) / (1.0 - float(beta1) ** int(step)))
     lr_t = f(f(lr) * lr_scale)
     b1, b2, e = f(beta1), f(beta2), f(eps)
-    c1, c2 = f(f(1) - b1), f(f(1) - b2)
+    c1, c2 = f(1.0 - float(beta1)), f(1.0 - float(beta2))   # Python doubles in the reference, rounded once
     mt = (b1 * m + c1 * g).astype(f)
     vt = (b2 * v + c2 * (g * g).astype(f)).astype(f)
     hn = (h - ((lr_t * mt).astype(f) / (np.sqrt(vt).astype(f) + e).astype(f)).astype(f)).astype(f)

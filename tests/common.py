@@ -82,4 +82,10 @@ def structured_rays(xs, ys, zlo=-0.1, zhi=0.6):
         d = np.array([dxy[0], dxy[1], -0.3])
         o = np.stack([X.ravel(), Y.ravel(), np.full(n, 0.25)]) - d[:, None] * 3
         out.append(np.concatenate([o, np.repeat(d[:, None], n, 1), np.full((1, n), np.inf)]))
-    return np.concatenate(out, 1).astype(np.float32)
+    out = np.concatenate(out, 1).astype(np.float32)
+    # the same families with negative zeros in the direction (d = -up is (-0,-0,-1)): 1/(-0) = -inf must not
+    # flip the slab tests of the walk
+    neg = out.copy()
+    z = neg[3:6] == 0
+    neg[3:6][z] = np.float32(-0.0)
+    return np.concatenate([out, neg], 1)

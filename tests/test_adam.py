@@ -12,7 +12,7 @@ def test_oracle_first_step_is_lr_sign_g(oracle):
     g = rng.normal(size=(7, 9)).astype(np.float32)
     hn, m, v = oracle.adam_step(h, g, np.zeros_like(h), np.zeros_like(h), lr=0.01, step=1)
     # m = (1-b1) g, v = (1-b2) g^2, lr_t = lr sqrt(1-b2)/(1-b1)  =>  step = lr g / (|g| + eps/sqrt(1-b2))
-    assert np.allclose(m, 0.1 * g, rtol=1e-6) and np.allclose(v, 0.001 * g * g, rtol=1e-4)
+    assert np.allclose(m, np.float32(0.1) * g, rtol=1e-6) and np.allclose(v, np.float32(0.001) * (g * g), rtol=1e-6)
     assert np.allclose(h - hn, 0.01 * np.sign(g), atol=1e-6)
 
 
