@@ -52,7 +52,7 @@ static unsigned long long *slot_acquire(const hf_field *hf, hipStream_t stream, 
     const uint32_t k = m->next_slot++ % HF_NUM_COUNTERS;
     if (m->slot_used[k]) (void) hipStreamWaitEvent(stream, m->slot_done[k], 0);
     *slot = k;
-    return m->d_counters + (size_t) k * 16; // 128 bytes apart
+    return m->d_counters + (size_t) k * HF_COUNTERS_PER_LAUNCH;
 }
 static void slot_release(const hf_field *hf, hipStream_t stream, uint32_t slot) {
     hf_field *m = const_cast<hf_field *>(hf);
@@ -175,7 +175,7 @@ extern "C" int hf_create(const hf_desc_t *desc, hf_field_t **out) {
     hipError_t e = hipMalloc((void **) &hf->d_heights, sizeof(float) * (size_t) d.W * d.H);
     if (e == hipSuccess) e = hipMalloc((void **) &hf->d_mip, sizeof(float2) * off);
     if (e == hipSuccess) e = hipMalloc((void **) &hf->d_shear, sizeof(float4) * 3 * (hf_shear_records(top) + 1));
-    if (e == hipSuccess) e = hipMalloc((void **) &hf->d_counters, sizeof(unsigned long long) * 16 * HF_NUM_COUNTERS);
+    if (e == hipSuccess) e = hipMalloc((void **) &hf->d_counters, sizeof(unsigned long long) * HF_COUNTERS_PER_LAUNCH * HF_NUM_COUNTERS);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&hf->built, hipEventDisableTiming);
     for (int k = 0; k < HF_NUM_COUNTERS && e == hipSuccess; ++k)
         e = hipEventCreateWithFlags(&hf->slot_done[k], hipEventDisableTiming);

@@ -115,6 +115,23 @@ __global__ __launch_bounds__(HF_BLOCK) void hf_shear_slope_kernel(int sh, float4
     rec[0].w = __builtin_fabsf(pl.x) + __builtin_fabsf(pl.y) + rmax;
 }
 
+// Levels above HF_SHEAR_TOP keep plain min/max boxes, stored in the same record form with the zero plane
+// (a = b = c = 0, slope factor 0: w = z, and shear_line leaves the ray's z line untouched bit for bit), so that
+// the per-lane walk reads every inner node through ONE code path -- three 16-byte loads from one address.
+// Children of node (ix,iy) of level L = nodes (2ix+jx, 2iy+jy) of depth k+1 of the pyramid (L >= 2).
+__global__ __launch_bounds__(HF_BLOCK) void hf_shear_minmax_kernel(const float2 *__restrict__ child, int sh,
+                                                                  float4 *__restrict__ out) {
+    const int node = blockIdx.x * HF_BLOCK + threadIdx.x;
+    if (node >= (1 << (2 * sh))) return;
+    const int iy = node >> sh, ix = node & ((1 << sh) - 1);
+    const float2 *c = child + ((size_t) (2 * iy) << (sh + 1)) + 2 * ix;
+    const float2 a = c[0], b = c[1], d = c[(size_t) 1 << (sh + 1)], e = c[((size_t) 1 << (sh + 1)) + 1];
+    float4 *rec = out + (size_t) node * 3;
+    rec[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+    rec[1] = make_float4(a.x, a.y, b.x, b.y);
+    rec[2] = make_float4(d.x, d.y, e.x, e.y);
+}
+
 void hf_launch_build_mips(const hf_dev_field &f, float2 *mip, float4 *shear, hipStream_t stream) {
     const int top = f.top;
     for (int L = 2; L <= top && L <= HF_SHEAR_TOP; ++L) {
@@ -133,6 +150,11 @@ void hf_launch_build_mips(const hf_dev_field &f, float2 *mip, float4 *shear, hip
         else
             hipLaunchKernelGGL(hf_mip_reduce_kernel, dim3(grid), dim3(HF_BLOCK), 0, stream,
                                (const float2 *) (mip + hf_depth_off(k + 1)), mip + hf_depth_off(k), k);
+    }
+    for (int L = HF_SHEAR_TOP + 1; L <= top; ++L) { // after the pyramid: reads depth k+1 of it
+        const int k = top - L, n = 1 << (2 * k);
+        hipLaunchKernelGGL(hf_shear_minmax_kernel, dim3((n + HF_BLOCK - 1) / HF_BLOCK), dim3(HF_BLOCK), 0, stream,
+                           (const float2 *) (mip + hf_depth_off(k + 1)), k, shear + (size_t) (hf_depth_off(k) - 1u) * 3);
     }
 }
 
@@ -362,13 +384,7 @@ struct hf_src_global {
         const uint32_t off = ((uint32_t) i * (uint32_t) W + (uint32_t) j) << 2;
         return *(const float *) ((const char *) h + off);
     }
-    // the two 16-byte halves (children 0,1 / 2,3) of the child boxes of inner node (ix,iy) of level L
-    __device__ __forceinline__ void children_ptrs(int L, uint32_t ix, uint32_t iy, const float4 *&a, const float4 *&b) const {
-        const uint32_t kd = (uint32_t) (top - (L - 1));
-        const uint32_t base = hf_depth_off((int) kd) + ((2u * iy) << kd) + 2u * ix;
-        a = (const float4 *) (mip + base); b = (const float4 *) (mip + base + (1u << kd));
-    }
-    // sheared record of node (ix,iy) of level L, 2 <= L <= HF_SHEAR_TOP
+    // record of inner node (ix,iy) of level L >= 2: plane + the four child ranges (hf_device.h)
     __device__ __forceinline__ const float4 *sheared(int L, uint32_t ix, uint32_t iy) const {
         const uint32_t k = (uint32_t) (top - L);
         return shear + (size_t) (hf_depth_off((int) k) - 1u + (iy << k) + ix) * 3;
@@ -421,19 +437,14 @@ __device__ __forceinline__ bool walk_subtree(const hf_dev_field &f, const Src &s
             const float Sc = 0.5f * S;
             const uint32_t ix = X ^ (fxm >> L), iy = Y ^ (fym >> L);
             hf_quad q;
-            float gz = r.gz, dz = r.dz, mz = r.mz;
-            const float4 *pa, *pb; // the child ranges are two 16-byte loads on either path
-            if (L <= HF_SHEAR_TOP) {
+            float gz, dz, mz;
+            {   // A wave-level gather returns when its slowest lane does (an L2 / Infinity Cache round trip, not an
+                // L1 hit), so the plane and the child ranges of the record are requested together: one memory round
+                // trip per visit.  Levels above HF_SHEAR_TOP carry the zero plane (hf_shear_minmax_kernel).
                 const float4 *rec = src.sheared(L, ix, iy);
-                const float4 pl = rec[0];
-                pa = rec + 1; pb = rec + 2;
+                const float4 pl = rec[0], q01 = rec[1], q23 = rec[2];
                 shear_line(f, rs, fx, fy, pl.x, pl.y, pl.z, pl.w, __builtin_fmaf((float) X, S, Sc),
                            __builtin_fmaf((float) Y, S, Sc), gz, dz, mz);
-            } else {
-                src.children_ptrs(L, ix, iy, pa, pb);
-            }
-            {
-                const float4 q01 = *pa, q23 = *pb;
                 q.lo[0] = q01.x; q.hi[0] = q01.y; q.lo[1] = q01.z; q.hi[1] = q01.w;
                 q.lo[2] = q23.x; q.hi[2] = q23.y; q.lo[3] = q23.z; q.hi[3] = q23.w;
             }
@@ -592,23 +603,23 @@ struct hf_si_dev {
 };
 
 // record stores are write-once streams (72 B/ray): non-temporal, so that they do not push the mip
-// and height lines of concurrently traversing waves out of L2
-__device__ __forceinline__ void st(float *p, size_t i, float v) { if (p) __builtin_nontemporal_store(v, &p[i]); }
-#define st3(p, i, v) do { st((p)[0], i, (v).x); st((p)[1], i, (v).y); st((p)[2], i, (v).z); } while (0)
+// and height lines of concurrently traversing waves out of L2.  Address = (row + ub) + lo: uniform base, lane offset.
+__device__ __forceinline__ void st(float *p, size_t ub, uint32_t lo, float v) { if (p) __builtin_nontemporal_store(v, &(p + ub)[lo]); }
+#define st3(p, ub, lo, v) do { st((p)[0], ub, lo, (v).x); st((p)[1], ub, lo, (v).y); st((p)[2], ub, lo, (v).z); } while (0)
 
 template <typename SiDev>
-__device__ __forceinline__ void store_si(const SiDev &out, size_t i, const hf_si_rec &si, uint32_t flags) {
-    st(out.t, i, si.t);
-    st3(out.p, i, si.p);
-    st3(out.n, i, si.n);
-    st(out.uv[0], i, si.uv0); st(out.uv[1], i, si.uv1);
-    st3(out.sh_n, i, si.sh_n);
-    st3(out.dp_du, i, si.dp_du);
-    st3(out.dp_dv, i, si.dp_dv);
-    if (flags & 0x40u) st(out.bt, i, si.boundary_test);
-    st3(out.sh_s, i, si.sh_s);
-    st3(out.sh_t, i, si.sh_t);
-    st3(out.wi, i, si.wi);
+__device__ __forceinline__ void store_si(const SiDev &out, size_t ub, uint32_t lo, const hf_si_rec &si, uint32_t flags) {
+    st(out.t, ub, lo, si.t);
+    st3(out.p, ub, lo, si.p);
+    st3(out.n, ub, lo, si.n);
+    st(out.uv[0], ub, lo, si.uv0); st(out.uv[1], ub, lo, si.uv1);
+    st3(out.sh_n, ub, lo, si.sh_n);
+    st3(out.dp_du, ub, lo, si.dp_du);
+    st3(out.dp_dv, ub, lo, si.dp_dv);
+    if (flags & 0x40u) st(out.bt, ub, lo, si.boundary_test);
+    st3(out.sh_s, ub, lo, si.sh_s);
+    st3(out.sh_t, ub, lo, si.sh_t);
+    st3(out.wi, ub, lo, si.wi);
 }
 
 // zero-initialised record for inactive / missed lanes (interaction.h:479-499, 667-673)
@@ -622,6 +633,14 @@ __device__ __forceinline__ void miss_si(hf_si_rec &si, v3 d, uint32_t flags) {
 }
 
 #define HF_GRAB 512 // most rays a wave takes from the work counter per fetch (hf_grab_for)
+#ifndef HF_DIST
+#define HF_DIST 2
+#endif
+#ifndef HF_TRACE_WAVES
+#define HF_TRACE_WAVES 5 // resident waves per SIMD = workgroups per CU of the traversal kernel (96 VGPRs)
+#endif
+#define HF_NUM_XCD 8u // work counters per launch, one per XCD (power of two)
+#define HF_COUNTER_STRIDE 16u // in counters: 128 bytes apart
 
 // the one kernel argument (kernarg segment offset 0)
 struct hf_trace_args {
@@ -635,6 +654,7 @@ struct hf_trace_args {
     uint32_t flags;
     uint32_t grab; // rays per fetch, a multiple of 64
     unsigned long long *counter;
+    unsigned long long n_grabs, band; // ceil(n / grab) grabs, in HF_NUM_XCD bands of `band` grabs
 };
 
 // member-wise copy out of the kernarg segment (constant address space)
@@ -648,61 +668,132 @@ __device__ __forceinline__ hf_dev_field load_field(const __attribute__((address_
     return f;
 }
 
+typedef const __attribute__((address_space(4))) hf_trace_args *hf_kargs_ptr;
+__device__ __forceinline__ hf_rays_dev load_rays(hf_kargs_ptr ka) {
+    hf_rays_dev r;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { r.o[k] = ka->rays.o[k]; r.d[k] = ka->rays.d[k]; }
+    r.maxt = ka->rays.maxt;
+    return r;
+}
+__device__ __forceinline__ hf_pi_dev load_pi(hf_kargs_ptr ka) {
+    hf_pi_dev p;
+    p.t = ka->pi.t; p.u = ka->pi.u; p.v = ka->pi.v; p.prim = ka->pi.prim;
+    return p;
+}
+__device__ __forceinline__ hf_si_dev load_si(hf_kargs_ptr ka) {
+    hf_si_dev d;
+    d.t = ka->sio.t; d.bt = ka->sio.bt;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        d.p[k] = ka->sio.p[k]; d.n[k] = ka->sio.n[k]; d.sh_n[k] = ka->sio.sh_n[k]; d.dp_du[k] = ka->sio.dp_du[k];
+        d.dp_dv[k] = ka->sio.dp_dv[k]; d.sh_s[k] = ka->sio.sh_s[k]; d.sh_t[k] = ka->sio.sh_t[k]; d.wi[k] = ka->sio.wi[k];
+    }
+    d.uv[0] = ka->sio.uv[0]; d.uv[1] = ka->sio.uv[1];
+    return d;
+}
+
 // Persistent waves: every wave pulls `grab` consecutive rays at a time from a global
 // counter (zeroed on the stream before the launch), so expensive image regions are
 // spread over all CUs whatever their position in the wavefront.
 template <int MODE>
-__global__ __launch_bounds__(HF_BLOCK, 4) void hf_trace_kernel(hf_trace_args a) {
+__global__ __launch_bounds__(HF_BLOCK, HF_TRACE_WAVES) void hf_trace_kernel(hf_trace_args a) {
     const hf_dev_field &f = a.f;
-    const size_t n = a.n;
-    const uint32_t flags = a.flags;
-    unsigned long long *counter = a.counter;
     __shared__ hf_lds_mips s;
     stage_mips(f, s);
     const unsigned lane = threadIdx.x & 63u;
-    // The counter hands out grab numbers; even grabs walk the wavefront from its front, odd ones from
-    // its back.  Rays that miss the bound only stream (memory/atomic-bound), rays that traverse are
-    // issue-bound: in rendered wavefronts the two come in large contiguous regions, and two fronts
-    // let them overlap in time instead of running one after the other.
-    const unsigned grab = a.grab;
-    const unsigned long long n_grabs = (n + grab - 1) / grab;
+    // Work distribution: the wavefront is cut into grabs of `grab` consecutive rays and the grabs into HF_NUM_XCD
+    // contiguous bands, one per XCD, each with its own counter (a single counter serves ~80 fetches/us, which capped
+    // the rays that only stream at half the memory bandwidth; eight addresses are served in parallel).  A wave pulls
+    // from the band of the XCD it runs on -- neighbouring pixels, hence neighbouring height / mip lines, stay in one
+    // L2 -- and moves on to the next band when its own is exhausted, so all XCDs finish together whatever the bands cost.
+    // (launch constants are read from the kernarg segment where they are needed -- see below -- so that the only
+    // scalar state alive across a walk is the band, the current grab and the position in it)
+    unsigned xc, tried = 0;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xc));
+    xc &= HF_NUM_XCD - 1u;
     for (;;) {
+        const __attribute__((address_space(4))) hf_trace_args *kg =
+            (const __attribute__((address_space(4))) hf_trace_args *) __builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(kg));
+        unsigned long long *counter = kg->counter;
+        const unsigned grab = kg->grab;
+        const unsigned long long n_grabs = kg->n_grabs, band = kg->band;
         unsigned long long g = 0;
-        if (lane == 0) g = atomicAdd(counter, 1ull);
+        if (lane == 0) g = atomicAdd(counter + (size_t) xc * HF_COUNTER_STRIDE, 1ull);
         g = ((unsigned long long) (uint32_t) __builtin_amdgcn_readfirstlane((int) (g >> 32)) << 32) |
             (unsigned long long) (uint32_t) __builtin_amdgcn_readfirstlane((int) (g & 0xffffffffull));
-        if (g >= n_grabs) break;
-        const unsigned long long base = ((g & 1ull) ? (n_grabs >> 1) - 1ull - (g >> 1) : (n_grabs >> 1) + (g >> 1)) * grab;
+#if HF_DIST == 0
+        const unsigned long long b0 = band * xc;
+        const unsigned long long bn = b0 >= n_grabs ? 0ull : (n_grabs - b0 < band ? n_grabs - b0 : band); // grabs of this band
+        if (g >= bn) { // band exhausted: steal from the next one; done when all have been seen exhausted
+            if (++tried == HF_NUM_XCD) break;
+            xc = (xc + 1u) & (HF_NUM_XCD - 1u);
+            continue;
+        }
+        const unsigned long long base = (b0 + g) * grab;
+#elif HF_DIST == 1
+        // interleaved: XCD x owns grabs x, x+8, x+16, ...
+        const unsigned long long gg = g * HF_NUM_XCD + xc;
+        if (gg >= n_grabs) {
+            if (++tried == HF_NUM_XCD) break;
+            xc = (xc + 1u) & (HF_NUM_XCD - 1u);
+            continue;
+        }
+        const unsigned long long base = gg * grab;
+        (void) band;
+#else
+        // interleaved + two fronts: even grabs walk from the middle to the end, odd ones from the middle to the front
+        const unsigned long long gg = g * HF_NUM_XCD + xc;
+        if (gg >= n_grabs) {
+            if (++tried == HF_NUM_XCD) break;
+            xc = (xc + 1u) & (HF_NUM_XCD - 1u);
+            continue;
+        }
+        const unsigned long long base = ((gg & 1ull) ? (n_grabs >> 1) - 1ull - (gg >> 1) : (n_grabs >> 1) + (gg >> 1)) * grab;
+        (void) band;
+#endif
+        // the ray of the batch in flight: requested one batch ahead (see below)
+        v3 o = mk3(0.f, 0.f, 0.f), d = o;
+        float maxt = 0.f;
 #pragma unroll 1
         for (unsigned sub = 0; sub < grab; sub += 64) {
             // all 64 lanes stay in the loop body (the shared walk relies on whole-wave ballots);
-            // lanes past the end of the wavefront re-read the last ray and store nothing
-            const size_t i_raw = base + sub + lane;
-            if (base + sub >= n) break; // wave-uniform
-            const bool valid = i_raw < n;
-            const size_t i = valid ? i_raw : n - 1;
+            // lanes past the end of the wavefront re-read the last ray and store nothing.
             // Pointers and constants that are only needed before or after the walk are read from the kernarg
             // segment where they are used: held in scalar registers across the walk they get spilled into
             // vector-register lanes, and fetching them back costs vector instructions.
             const __attribute__((address_space(4))) hf_trace_args *ka =
                 (const __attribute__((address_space(4))) hf_trace_args *) __builtin_amdgcn_kernarg_segment_ptr();
             asm volatile("" : "+s"(ka)); // opaque: keeps these loads inside the loop body
-            const v3 o = mk3(ka->rays.o[0][i], ka->rays.o[1][i], ka->rays.o[2][i]);
-            const v3 d = mk3(ka->rays.d[0][i], ka->rays.d[1][i], ka->rays.d[2][i]);
-            const float maxt = ka->rays.maxt[i];
+            const size_t n = ka->n;
+            // Addressing: every array is read / written at  (pointer + ub) + lo  with the wave-uniform element
+            // offset ub and a 32-bit lane offset lo -- scalar base + vector offset, no 64-bit vector arithmetic.
+            const size_t ub = base + sub;
+            if (ub >= n) break; // wave-uniform
+            const size_t left = n - ub; // >= 1
+            const bool valid = lane < left;
+            const uint32_t lo = valid ? lane : (uint32_t) (left - 1);
+            if (sub == 0) {
+                const hf_rays_dev rp = load_rays(ka);
+                o = mk3((rp.o[0] + ub)[lo], (rp.o[1] + ub)[lo], (rp.o[2] + ub)[lo]);
+                d = mk3((rp.d[0] + ub)[lo], (rp.d[1] + ub)[lo], (rp.d[2] + ub)[lo]);
+                maxt = (rp.maxt + ub)[lo];
+            }
             hf_hit best;
             best.hit = false; best.t = __builtin_inff(); best.u = 0.f; best.v = 0.f; best.prim = 0u;
             const uint8_t *active = ka->active;
-            const bool act = valid && (active ? (active[i] != 0) : true);
+            const bool act = valid && (active ? ((active + ub)[lo] != 0) : true);
 #ifdef HF_TSTATS
             const long long tb0 = clock64();
 #endif
-            hf_ray_state rs;
+            hf_ray_state rs = {}; // fully defined on every path: undefined fields become loop-carried registers
             bool alive;
             {
                 const hf_dev_field f0 = load_field(&ka->f); // to_object etc.
                 alive = act && setup_ray(f0, s.node[1], o, d, maxt, rs);
             }
+            const v3 dw = d; // world-space direction: wi of the record
             const uint64_t am = __ballot(alive);
             if (am != 0ull) {
                 // coherent wave?  equal direction signs, entry points and directions close to the first live lane's
@@ -724,26 +815,44 @@ __global__ __launch_bounds__(HF_BLOCK, 4) void hf_trace_kernel(hf_trace_args a) 
                 if (alive) { best.t = (float) (clock64() - tb0); best.v = (float) (tb1 - tb0); }
 #endif
             }
-            if (!valid) continue;
             asm volatile("" : "+s"(ka)); // the ~30 output pointers: loaded here, not before the walk
+            // Request the next batch's rays BEFORE this batch's records are stored: vector-memory operations
+            // complete in order, so a wave that loads after its stores waits for the store acknowledgements
+            // (HBM write latency) on top of its own load latency -- that serial chain, not bandwidth, bounded
+            // the rays that only stream.
+            if (sub + 64 < grab && ub + 64 < n) {
+                const size_t ub2 = ub + 64, left2 = n - ub2;
+                const uint32_t lo2 = lane < left2 ? lane : (uint32_t) (left2 - 1);
+                const hf_rays_dev rp = load_rays(ka);
+                o = mk3((rp.o[0] + ub2)[lo2], (rp.o[1] + ub2)[lo2], (rp.o[2] + ub2)[lo2]);
+                d = mk3((rp.d[0] + ub2)[lo2], (rp.d[1] + ub2)[lo2], (rp.d[2] + ub2)[lo2]);
+                maxt = (rp.maxt + ub2)[lo2];
+            } else { // (defined on this path too, or the old values stay live across the walk)
+                o = mk3(0.f, 0.f, 0.f); d = o; maxt = 0.f;
+            }
+            if (!valid) continue;
             if (MODE == 1) {
                 uint8_t *hit_out = ka->hit_out;
-                hit_out[i] = best.hit ? 1 : 0;
+                (hit_out + ub)[lo] = best.hit ? 1 : 0;
             } else {
-                hf_pi_dev pi;
-                pi.t = ka->pi.t; pi.u = ka->pi.u; pi.v = ka->pi.v; pi.prim = ka->pi.prim;
-                if (pi.t) pi.t[i] = best.hit ? best.t : __builtin_inff();
-                if (pi.u) pi.u[i] = best.hit ? best.u : 0.f;
-                if (pi.v) pi.v[i] = best.hit ? best.v : 0.f;
-                if (pi.prim) pi.prim[i] = best.hit ? best.prim : 0u;
+                const hf_pi_dev pi = load_pi(ka);
+                if (pi.t) (pi.t + ub)[lo] = best.hit ? best.t : __builtin_inff();
+                if (pi.u) (pi.u + ub)[lo] = best.hit ? best.u : 0.f;
+                if (pi.v) (pi.v + ub)[lo] = best.hit ? best.v : 0.f;
+                if (pi.prim) (pi.prim + ub)[lo] = best.hit ? best.prim : 0u;
                 if (MODE == 2) {
                     hf_si_rec si;
+                    const uint32_t flags = ka->flags;
                     if (best.hit) {
+                        // the origin is only needed by a hit: read again (an L2 hit) rather than held across the walk
+                        const hf_rays_dev rp = load_rays(ka);
+                        const v3 ow = mk3((rp.o[0] + ub)[lo], (rp.o[1] + ub)[lo], (rp.o[2] + ub)[lo]);
                         const hf_dev_field fl = load_field(&ka->f); // to_world etc.: not held across the walk
-                        compute_si(fl, o, d, best.t, best.u, best.v, best.prim, flags, si);
+                        compute_si(fl, ow, dw, best.t, best.u, best.v, best.prim, flags, si);
                     }
-                    else          miss_si(si, d, flags);
-                    store_si(ka->sio, i, si, flags);
+                    else          miss_si(si, dw, flags);
+                    const hf_si_dev sio = load_si(ka); // all row pointers at once (wide scalar loads), then the stores
+                    store_si(sio, ub, lo, si, flags);
                 }
             }
         }
@@ -780,7 +889,7 @@ static hf_si_dev to_dev(const hf_si_t *s) {
 // rays that only stream), fewer for small ones so that every resident wave gets several fetches --
 // a fetch of 512 traversing rays is ~0.4 ms of work, the whole launch for a 4 M-ray wavefront.
 static uint32_t hf_grab_for(size_t n) {
-    const size_t resident = 256 * 4 * 4;         // waves the launch keeps on the chip
+    const size_t resident = 256 * 4 * HF_TRACE_WAVES; // waves the launch keeps on the chip
     size_t g = (n / (resident * 4) + 63) / 64 * 64; // ~4 fetches per wave
     if (g < 64) g = 64;
     if (g > HF_GRAB) g = HF_GRAB;
@@ -791,7 +900,7 @@ void hf_launch_trace(int mode, const hf_dev_field &f, size_t n, const hf_rays_t 
                      const hf_pi_t *pi, uint8_t *hit, const hf_si_t *si, uint32_t flags, unsigned long long *counter,
                      hipStream_t stream) {
     if (n == 0) return;
-    (void) hipMemsetAsync(counter, 0, sizeof(unsigned long long), stream);
+    (void) hipMemsetAsync(counter, 0, sizeof(unsigned long long) * HF_NUM_XCD * HF_COUNTER_STRIDE, stream);
     hf_pi_dev p = { nullptr, nullptr, nullptr, nullptr };
     if (pi) { p.t = pi->t; p.u = pi->prim_uv[0]; p.v = pi->prim_uv[1]; p.prim = pi->prim_index; }
     hf_si_dev sd;
@@ -800,11 +909,12 @@ void hf_launch_trace(int mode, const hf_dev_field &f, size_t n, const hf_rays_t 
     const hf_rays_dev r = to_dev(rays);
     const uint32_t grab = hf_grab_for(n);
     size_t waves = (n + grab - 1) / grab, blocks = (waves + 3) / 4;
-    if (blocks > 256 * 4) blocks = 256 * 4; // 4 resident workgroups per CU (128 VGPRs)
+    if (blocks > 256 * HF_TRACE_WAVES) blocks = 256 * HF_TRACE_WAVES; // the resident set: HF_TRACE_WAVES workgroups per CU
     const dim3 grid((unsigned) blocks), block(HF_BLOCK);
     hf_trace_args a;
     a.f = f; a.n = n; a.rays = r; a.active = active; a.pi = p; a.hit_out = hit; a.sio = sd; a.flags = flags;
     a.counter = counter; a.grab = grab;
+    a.n_grabs = waves; a.band = (waves + HF_NUM_XCD - 1) / HF_NUM_XCD;
     if (mode == 0)
         hipLaunchKernelGGL(hf_trace_kernel<0>, grid, block, 0, stream, a);
     else if (mode == 1)
@@ -833,7 +943,7 @@ __global__ __launch_bounds__(HF_BLOCK) void hf_si_kernel(hf_dev_field f, size_t 
         hf_si_rec si;
         if (act) compute_si(f, o, d, t, pi.u[i], pi.v[i], pi.prim[i], flags, si);
         else     miss_si(si, d, flags);
-        store_si(sio, i, si, flags);
+        store_si(sio, i, 0u, si, flags);
     }
 }
 

@@ -6,6 +6,8 @@
 #include "hf_device.h"
 
 void hf_launch_build_mips(const hf_dev_field &f, float2 *mip, float4 *shear, hipStream_t stream);
+// counters a trace launch needs (zeroed by the launcher): one per XCD, 128 bytes apart
+#define HF_COUNTERS_PER_LAUNCH (8 * 16)
 // mode 0: closest hit -> pi; 1: any hit -> hit; 2: closest hit + fused surface interaction
 void hf_launch_trace(int mode, const hf_dev_field &f, size_t n, const hf_rays_t *rays, const uint8_t *active,
                      const hf_pi_t *pi, uint8_t *hit, const hf_si_t *si, uint32_t flags, unsigned long long *counter,

@@ -55,6 +55,21 @@ if any(k.startswith("sec") for k in a.kinds):
     nrays = {"sec_fwd": Rs, "sec_test": Rs}
 else:
     nrays = {}
+if any(k.startswith("alive") for k in a.kinds):
+    # the rays that enter the (identity to_world) bound, compacted in wavefront order: what a traversal kernel
+    # behind a cull + compact pre-pass would see
+    bb = shape.bbox().to(dev)
+    lo = torch.tensor([-1.0 - 1e-4, -1.0 - 1e-4, float(bb[0, 2]) - 1e-5], device=dev)[:, None]
+    hi = torch.tensor([1.0 + 1e-4, 1.0 + 1e-4, float(bb[1, 2]) + 1e-5], device=dev)[:, None]
+    inv = 1.0 / rays[3:6]
+    t1, t2 = (lo - rays[0:3]) * inv, (hi - rays[0:3]) * inv
+    tin = torch.minimum(t1, t2).max(0).values.clamp(min=0); tout = torch.minimum(torch.maximum(t1, t2).min(0).values, rays[6])
+    alive_idx = torch.nonzero(tin <= tout).squeeze(1)
+    ar = rays[:, alive_idx].contiguous(); Ra = ar.shape[1]
+    a_s = shape._rays_struct(ar[0:3], ar[3:6], ar[6])
+    fn["alive_fwd"] = lambda: _capi.check(lib.hf_ray_intersect(shape._h, Ra, C.byref(a_s), flags, None, C.byref(pi_s), C.byref(si_s), st))
+    fn["alive_prelim"] = lambda: _capi.check(lib.hf_ray_intersect_preliminary(shape._h, Ra, C.byref(a_s), None, C.byref(pi_s), st))
+    nrays.update({"alive_fwd": Ra, "alive_prelim": Ra})
 if "reparam" in a.kinds:
     # backward of reparameterize_ray (4 auxiliary rays per primary ray: 8 fused traces + 8 weight kernels + 4 adjoints)
     hfp = shape.heightfield.requires_grad_(True)
