@@ -6,9 +6,12 @@ One step = one pass of the hot path over one ray wavefront:
     adjoint  : hf_adjoint        (reverse mode of the SI, atomic scatter of dL/dheight)
                [+ one RCCL all-reduce of the N x N gradient texture when world_size > 1]
 Workload (BASELINE.json configs[3] / SURVEY.md 8d): 4096^2 procedural sine heightfield,
-1024x1024 orthographic sensor @ 64 spp = 67 108 864 rays per GPU; at N > 1 every rank traces
-its own 64 spp of the same image (rays shard over pixels x spp; weak scaling), heights and
-mips are replicated and the gradient texture is summed with one all-reduce per step.
+1024x1024 orthographic sensor @ 64 spp = ONE wavefront of 67 108 864 rays.  At N > 1 the wavefront is cut into
+32x32-pixel image tiles, tile b -> rank b % N (hf_amd.workload.partition_tiles; src/render/integrator.cpp:
+130-140), i.e. STRONG scaling: total work fixed, `value` = 67.1 M rays / step time.  Heights and acceleration
+data are replicated; every rank accumulates a private gradient texture and the textures are summed with one
+all-reduce per step, issued asynchronously so that it overlaps the next step's forward + adjoint (double-
+buffered texture).  `--scaling weak` keeps the round-1 mode (every rank traces its own 64 spp of the image).
 
 Launch:  python bench.py [--gpus N --steps K --warmup W]
          python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
@@ -30,6 +33,7 @@ FWD_BYTES_PER_RAY = 104.0   # 28 ray in + 72 SI out + 4 prim_index out
 ADJ_BYTES_PER_RAY = 128.0   # 28 ray + 16 pi + 72 upstream in + 12 atomically added
 GRID_BYTES_PER_TEXEL = 20.0 / 3.0  # heights 4 B + mips ~8/3 B, read once per pass
 HBM_PEAK_GBS = 8000.0       # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_COPY_GBS = 6290.0       # same guide: measured float4 copy (79 % of spec)
 
 
 def parse():
@@ -41,6 +45,8 @@ def parse():
     ap.add_argument("--film", type=int, default=1024)
     ap.add_argument("--spp", type=int, default=64)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline time (0 = skip)")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="N > 1: strong = image tiles of ONE wavefront (configs[3]); weak = a full wavefront per rank")
     return ap.parse_args()
 
 
@@ -72,19 +78,26 @@ def main():
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     N, Wf, spp = args.grid, args.film, args.spp
-    R = Wf * Wf * spp
+    R_total = Wf * Wf * spp
+    strong = world > 1 and args.scaling == "strong"
     lib = _capi.lib()
 
     # ---- inputs, resident in HBM before any timed region --------------------------------
     heights = hf_amd.workload.sine_heights(N, N, device=dev)
     shape = hf_amd.Heightfield(heightfield=heights, max_height=0.5)
-    rays = hf_amd.workload.ortho_rays(Wf, Wf, spp, dev, seed=rank)      # [7, R]
+    if strong:   # this rank's image tiles of the one wavefront
+        my_pixels = hf_amd.workload.partition_tiles(Wf, Wf, world)[rank]
+        rays = hf_amd.workload.ortho_rays(Wf, Wf, spp, dev, pixels=my_pixels)   # [7, R]
+    else:
+        rays = hf_amd.workload.ortho_rays(Wf, Wf, spp, dev, seed=rank)          # [7, R]
+    R = rays.shape[1]
     t = torch.empty(R, dtype=torch.float32, device=dev)
     uv = torch.empty((2, R), dtype=torch.float32, device=dev)
     prim = torch.empty(R, dtype=torch.int32, device=dev)
     si = torch.empty((18, R), dtype=torch.float32, device=dev)           # t,p,n,uv,sh_n,dp_du,dp_dv = 72 B/ray
     gsi = torch.zeros((18, R), dtype=torch.float32, device=dev)          # upstream dL/dsi, 72 B/ray
-    grad_h = torch.zeros((N, N), dtype=torch.float32, device=dev)
+    grads = [torch.zeros((N, N), dtype=torch.float32, device=dev) for _ in range(2 if world > 1 else 1)]
+    pending = [None, None]                                               # outstanding all-reduce per buffer
     stream = torch.cuda.current_stream(dev).cuda_stream
 
     r_s = shape._rays_struct(rays[0:3], rays[3:6], rays[6])
@@ -92,16 +105,28 @@ def main():
     si_s = _fill(_capi.hf_si_t(), _DIFF_ROWS, _rows(si, R))
     g_s = _fill(_capi.hf_si_grad_t(), _DIFF_ROWS, _rows(gsi, R))
     flags = int(hf_amd.RayFlags.All)
+    step_no = [0]
 
     def forward():
         _capi.check(lib.hf_ray_intersect(shape._h, R, C.byref(r_s), flags, None, C.byref(pi_s), C.byref(si_s), stream))
 
     def adjoint():
+        b = step_no[0] % len(grads)
+        step_no[0] += 1
+        if pending[b] is not None:        # the all-reduce that used this buffer two steps ago
+            pending[b].wait(); pending[b] = None
+        grad_h = grads[b]
         grad_h.zero_()
         _capi.check(lib.hf_adjoint(shape._h, R, C.byref(r_s), C.byref(pi_s), flags, None, C.byref(g_s),
                                    grad_h.data_ptr(), None, None, stream))
-        if world > 1:
-            dist.all_reduce(grad_h)
+        if world > 1:                     # one collective per step, overlapping the next step's kernels
+            pending[b] = dist.all_reduce(grad_h, async_op=True)
+        return grad_h
+
+    def drain():
+        for b in range(len(pending)):
+            if pending[b] is not None:
+                pending[b].wait(); pending[b] = None
 
     # closed-form upstream gradient of SURVEY 8d: dL/dt = 1, dL/dp = n, rest 0
     forward()
@@ -125,6 +150,7 @@ def main():
 
     for _ in range(args.warmup):
         step(False)
+    drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -132,6 +158,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(True)
+    drain()                               # the last all-reduce belongs to the timed region
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -143,7 +170,14 @@ def main():
         elapsed = float(tt.item())
 
     ms_step = 1e3 * elapsed / args.steps
-    total_rays = float(R) * world
+    grad_h = grads[(step_no[0] - 1) % len(grads)]
+    if world > 1:   # whole-job ray count: the one wavefront (strong) or one wavefront per rank (weak)
+        rr = torch.tensor([float(R)], dtype=torch.float64, device=dev)
+        dist.all_reduce(rr)
+        total_rays = float(rr.item())
+        assert not strong or int(total_rays) == R_total
+    else:
+        total_rays = float(R)
     value = total_rays / (elapsed / args.steps) / 1e6  # Mrays/s, whole job
     fwd_ms = sum(a.elapsed_time(b) for a, b in fwd_ev) / len(fwd_ev)
     adj_ms = sum(a.elapsed_time(b) for a, b in adj_ev) / len(adj_ev)
@@ -154,24 +188,35 @@ def main():
 
     out = None
     if rank == 0:
-        # roofline of the dominant kernel (forward traversal+SI, hf_trace_kernel<2>)
+        # roofline of the dominant kernel.  ALGORITHMIC bytes (SURVEY 8d contract figures):
+        #   forward, every ray: 28 B ray in + 72 B SI + 4 B prim_index out, + the grid once per pass
+        #   adjoint: a ray that hit reads ray 28 + pi 16 + upstream 72 and adds 12 B; a ray that missed is
+        #            recognised from pi.t (4 B) and skipped -- counting 128 B for it would credit bytes never moved
+        n_hit = hit_frac * R
         fwd_bytes = R * FWD_BYTES_PER_RAY + N * N * GRID_BYTES_PER_TEXEL
-        adj_bytes = R * ADJ_BYTES_PER_RAY + N * N * 4.0
+        adj_bytes = n_hit * ADJ_BYTES_PER_RAY + (R - n_hit) * 4.0 + N * N * 4.0
         dom_ms, dom_bytes, dom_name = (fwd_ms, fwd_bytes, "hf_trace_kernel<2>") if fwd_ms >= adj_ms else \
                                       (adj_ms, adj_bytes, "hf_adjoint_kernel")
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
-        traffic = None
+        # counter-measured HBM traffic of that kernel, only when the profile it came from was taken at this commit
+        traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(dom_name, {}).get("hbm_bytes_per_launch")
+                tj = json.load(open(tpath))
+                traffic = tj.get(dom_name, {}).get("hbm_bytes_per_launch")
+                traffic_src = tj.get("source")
             except Exception:
                 traffic = None
         roofline = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                    "frac_of_measured_copy_peak": round(achieved / HBM_COPY_GBS, 5),
+                    "traffic": traffic, "traffic_source": traffic_src,
                     "avg_launch_ms": round(dom_ms, 4),
                     "fwd_ms": round(fwd_ms, 4), "adj_ms": round(adj_ms, 4),
-                    "fwd_adj_frac": round(((fwd_bytes + adj_bytes) / ((fwd_ms + adj_ms) * 1e-3) / 1e9) / HBM_PEAK_GBS, 5)}
+                    "fwd_frac": round(fwd_bytes / (fwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                    "adj_frac": round(adj_bytes / (adj_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                    "algorithmic_bytes": {"forward": fwd_bytes, "adjoint": adj_bytes}}
         extras = None
         if world == 1 and os.environ.get("HF_BENCH_EXTRAS", "1") != "0":  # profile_round.sh switches them off
             extras = other_launches(torch, hf_amd, _capi, lib, shape, r_s, pi_s, si_s, si, R, stream, flags)
@@ -180,12 +225,16 @@ def main():
             cpu = cpu_baseline(args, heights.cpu().numpy(), rays, gsi, R)
         out = {"metric": "Mrays/s forward+adjoint on 4096^2 heightfield", "value": round(value, 2),
                "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak",
+               "ms_per_step": round(ms_step, 4), "higher_is_better": True,
+               "scaling": "strong" if (strong or world == 1) else "weak",
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": f"{N}x{N} sine heightfield, {Wf}x{Wf} orthographic sensor @{spp}spp "
-                                      f"= {R} rays/GPU, forward(ray_intersect, RayFlags.All)+adjoint(dL/dheight)",
-                          "rays_per_gpu": R, "hit_fraction": round(hit_frac, 4),
-                          "parallelism": f"rays sharded over {world} GPU(s), 1 all-reduce of the grad texture"},
+                                      f"= {int(total_rays)} rays per step, forward(ray_intersect, RayFlags.All)"
+                                      f"+adjoint(dL/dheight)",
+                          "rays_rank0": R, "rays_per_step": int(total_rays), "hit_fraction_rank0": round(hit_frac, 4),
+                          "parallelism": (f"one wavefront in 32x32-pixel tiles, tile b -> rank b % {world}; "
+                                          if strong else f"one wavefront per rank ({world}); ") +
+                                         "heights replicated, 1 async all-reduce of the gradient texture per step"},
                "roofline": roofline, "cpu_baseline": cpu, "other_launches_ms": extras}
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -282,6 +282,35 @@ int hf_reparam_weights(int mode, size_t n, const float *const o[3], const float 
                        float *Z, float *const dZ[3], const float *const grad_direction[3],
                        const float *grad_divergence, float *const grad_p[3], float *grad_t, hf_stream_t stream);
 
+/* ---- scalar / packet entry -----------------------------------------------------
+ * Shape::ray_intersect_preliminary_scalar / _packet and ray_test_scalar / _packet
+ * (include/mitsuba/render/shape.h:220-240, wrapper macros :594-641): the forms the scalar and LLVM
+ * variants call per kd-tree leaf (include/mitsuba/render/kdtree.h:2490-2520) and from Embree's user-geometry
+ * callbacks (src/render/shape.cpp:125-223) with 1, 4, 8 or 16 rays held in HOST registers.  These two entry
+ * points take HOST pointers (SoA, n <= HF_PACKET_MAX), stage the packet through a per-thread pinned buffer and
+ * a per-thread stream, run the same traversal kernel and return when the results are back in the host arrays
+ * (synchronous, thread-safe, any number of threads).  One call costs a kernel launch and two PCIe round trips
+ * (tens of microseconds): it exists so that an adapter can serve those call sites with the SAME arithmetic;
+ * a renderer should hand whole wavefronts to the device entry points above.  `active` NULL = all lanes.
+ * Inactive / missed lanes: t = +inf, prim_uv = 0, prim_index = 0; hit = 0. */
+#define HF_PACKET_MAX 16
+int hf_ray_intersect_preliminary_packet(const hf_field_t *hf, uint32_t n, const float *const h_o[3],
+                                        const float *const h_d[3], const float *h_maxt, const uint8_t *h_active,
+                                        float *h_t, float *const h_prim_uv[2], uint32_t *h_prim_index);
+int hf_ray_test_packet(const hf_field_t *hf, uint32_t n, const float *const h_o[3], const float *const h_d[3],
+                       const float *h_maxt, const uint8_t *h_active, uint8_t *h_hit);
+
+/* ---- multi-GPU -------------------------------------------------------------------
+ * Rays shard over image tiles, heights and acceleration data are replicated, every GPU accumulates a private
+ * dL/dheight texture; this is the ONE collective of the path: an in-place sum all-reduce (float32) of that
+ * texture over RCCL / xGMI, enqueued on `stream` (so it is ordered after the hf_adjoint launches of that stream
+ * and can overlap the next wavefront's forward pass running on another stream).
+ * `rccl_comm` is the caller's ncclComm_t for this rank (ncclCommInitRank by the host application), as void*.
+ * RCCL is bound at first use: the ncclAllReduce already present in the process (the host's own RCCL, so that
+ * the communicator and the call come from the same library), otherwise librccl.so is loaded.
+ * Returns HF_EDEVICE if RCCL cannot be found or reports an error. */
+int hf_allreduce_grad(float *d_grad, size_t count, void *rccl_comm, hf_stream_t stream);
+
 /* ---- introspection (tests / tools) --------------------------------------------- */
 int hf_num_levels(const hf_field_t *hf);
 /* copies mip level `level` (1..num_levels) to HOST memory as (min,max) pairs,

@@ -36,7 +36,7 @@ def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB_PATH
     cmd = [_hipcc()] + FLAGS + ["-I", os.path.join(PKG_DIR, "..", "include")] + \
-          [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB_PATH]
+          [os.path.join(CSRC, s) for s in SOURCES] + ["-ldl", "-o", LIB_PATH]   # dl: RCCL is bound at first use
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -1,5 +1,6 @@
 // hf_capi.cpp -- the C ABI of libhf (include/hf.h): handle management, argument
 // validation, error strings.  All device work is in hf_kernels.hip.
+#include <dlfcn.h>
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -518,5 +519,147 @@ extern "C" int hf_reparam_weights(int mode, size_t n, const float *const o[3], c
     }
     hf_launch_reparam_weights(a, (hipStream_t) stream);
     HF_HIP(hipGetLastError());
+    return HF_OK;
+}
+
+// ---- scalar / packet entry: host pointers, per-thread staging ------------------------
+namespace {
+// layout of the staging block, in floats: 7 ray rows, t, u, v, prim (u32), then HF_PACKET_MAX bytes of mask / hit
+enum { PK_ROWS = 11, PK_FLOATS = PK_ROWS * HF_PACKET_MAX, PK_BYTES = PK_FLOATS * 4 + 2 * HF_PACKET_MAX };
+struct packet_stage {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    char *h = nullptr, *d = nullptr; // pinned host mirror, device block
+    void release() {
+        if (device < 0) return;
+        hf_device_guard guard(device);
+        if (stream) (void) hipStreamDestroy(stream);
+        if (h) (void) hipHostFree(h);
+        if (d) (void) hipFree(d);
+        device = -1; stream = nullptr; h = d = nullptr;
+    }
+    ~packet_stage() { release(); }
+};
+thread_local packet_stage g_stage;
+
+int stage_for(const char *fn, int device, packet_stage **out) {
+    packet_stage &s = g_stage;
+    if (s.device != device) {
+        s.release();
+        hipError_t e = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipHostMalloc((void **) &s.h, PK_BYTES, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipMalloc((void **) &s.d, PK_BYTES);
+        if (e != hipSuccess) {
+            s.device = device; // so that release() frees what exists
+            s.release();
+            return fail(e == hipErrorOutOfMemory ? HF_ENOMEM : HF_EDEVICE, "%s: %s", fn, hipGetErrorString(e));
+        }
+        s.device = device;
+    }
+    *out = &s;
+    return HF_OK;
+}
+
+// mode 0: closest hit, mode 1: any hit
+int packet_trace(const char *fn, int mode, const hf_field_t *hf, uint32_t n, const float *const h_o[3],
+                 const float *const h_d[3], const float *h_maxt, const uint8_t *h_active, float *h_t,
+                 float *const h_uv[2], uint32_t *h_prim, uint8_t *h_hit) {
+    if (!hf || !h_o || !h_d || !h_maxt) return fail(HF_EINVAL, "%s: NULL argument", fn);
+    if (n == 0) return HF_OK;
+    if (n > HF_PACKET_MAX) return fail(HF_EINVAL, "%s: packet of %u rays (at most %d)", fn, n, HF_PACKET_MAX);
+    for (int k = 0; k < 3; ++k)
+        if (!h_o[k] || !h_d[k]) return fail(HF_EINVAL, "%s: NULL ray component array", fn);
+    hf_device_guard guard(hf->device);
+    if (!guard.ok) return fail(HF_EDEVICE, "%s: cannot select device %d", fn, hf->device);
+    packet_stage *st;
+    int rc = stage_for(fn, hf->device, &st);
+    if (rc) return rc;
+    float *hf32 = (float *) st->h;
+    for (int k = 0; k < 3; ++k) {
+        memcpy(hf32 + (size_t) k * HF_PACKET_MAX, h_o[k], sizeof(float) * n);
+        memcpy(hf32 + (size_t) (3 + k) * HF_PACKET_MAX, h_d[k], sizeof(float) * n);
+    }
+    memcpy(hf32 + 6 * HF_PACKET_MAX, h_maxt, sizeof(float) * n);
+    uint8_t *hmask = (uint8_t *) (st->h + PK_FLOATS * 4), *hhit = hmask + HF_PACKET_MAX;
+    for (uint32_t k = 0; k < n; ++k) hmask[k] = h_active ? h_active[k] : 1;
+    float *d32 = (float *) st->d;
+    uint8_t *dmask = (uint8_t *) (st->d + PK_FLOATS * 4), *dhit = dmask + HF_PACKET_MAX;
+    HF_HIP(hipStreamWaitEvent(st->stream, hf->built, 0)); // the last rebuild of the acceleration data
+    HF_HIP(hipMemcpyAsync(st->d, st->h, PK_BYTES, hipMemcpyHostToDevice, st->stream));
+    hf_rays_t rays;
+    for (int k = 0; k < 3; ++k) { rays.o[k] = d32 + (size_t) k * HF_PACKET_MAX; rays.d[k] = d32 + (size_t) (3 + k) * HF_PACKET_MAX; }
+    rays.maxt = d32 + 6 * HF_PACKET_MAX;
+    hf_pi_t pi;
+    pi.t = d32 + 7 * HF_PACKET_MAX; pi.prim_uv[0] = d32 + 8 * HF_PACKET_MAX; pi.prim_uv[1] = d32 + 9 * HF_PACKET_MAX;
+    pi.prim_index = (uint32_t *) (d32 + 10 * HF_PACKET_MAX);
+    {
+        uint32_t slot;
+        unsigned long long *counter = slot_acquire(hf, st->stream, &slot);
+        hf_launch_trace(mode, hf->dev, n, &rays, dmask, mode == 0 ? &pi : nullptr, mode == 1 ? dhit : nullptr, nullptr, 0,
+                        counter, st->stream);
+        slot_release(hf, st->stream, slot);
+    }
+    HF_HIP(hipGetLastError());
+    HF_HIP(hipMemcpyAsync(st->h, st->d, PK_BYTES, hipMemcpyDeviceToHost, st->stream));
+    HF_HIP(hipStreamSynchronize(st->stream));
+    if (mode == 0) {
+        if (h_t) memcpy(h_t, hf32 + 7 * HF_PACKET_MAX, sizeof(float) * n);
+        if (h_uv && h_uv[0]) memcpy(h_uv[0], hf32 + 8 * HF_PACKET_MAX, sizeof(float) * n);
+        if (h_uv && h_uv[1]) memcpy(h_uv[1], hf32 + 9 * HF_PACKET_MAX, sizeof(float) * n);
+        if (h_prim) memcpy(h_prim, hf32 + 10 * HF_PACKET_MAX, sizeof(uint32_t) * n);
+    } else {
+        memcpy(h_hit, hhit, n);
+    }
+    return HF_OK;
+}
+} // namespace
+
+extern "C" int hf_ray_intersect_preliminary_packet(const hf_field_t *hf, uint32_t n, const float *const h_o[3],
+                                                   const float *const h_d[3], const float *h_maxt,
+                                                   const uint8_t *h_active, float *h_t, float *const h_prim_uv[2],
+                                                   uint32_t *h_prim_index) {
+    if (n && !h_t) return fail(HF_EINVAL, "hf_ray_intersect_preliminary_packet: NULL output");
+    return packet_trace("hf_ray_intersect_preliminary_packet", 0, hf, n, h_o, h_d, h_maxt, h_active, h_t, h_prim_uv,
+                        h_prim_index, nullptr);
+}
+
+extern "C" int hf_ray_test_packet(const hf_field_t *hf, uint32_t n, const float *const h_o[3],
+                                  const float *const h_d[3], const float *h_maxt, const uint8_t *h_active,
+                                  uint8_t *h_hit) {
+    if (n && !h_hit) return fail(HF_EINVAL, "hf_ray_test_packet: NULL output");
+    return packet_trace("hf_ray_test_packet", 1, hf, n, h_o, h_d, h_maxt, h_active, nullptr, nullptr, nullptr, h_hit);
+}
+
+// ---- multi-GPU: the one collective of the path --------------------------------------------
+namespace {
+typedef int (*nccl_allreduce_fn)(const void *, void *, size_t, int, int, void *, hipStream_t);
+typedef const char *(*nccl_errstr_fn)(int);
+nccl_allreduce_fn g_allreduce = nullptr;
+nccl_errstr_fn g_nccl_errstr = nullptr;
+std::once_flag g_nccl_once;
+void bind_rccl() {
+    // the host's own RCCL first (communicator and call must come from one library), else the system library
+    void *sym = dlsym(RTLD_DEFAULT, "ncclAllReduce");
+    void *lib = nullptr;
+    if (!sym) {
+        const char *names[] = { "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so" };
+        for (const char *nm : names)
+            if ((lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL))) break;
+        if (lib) sym = dlsym(lib, "ncclAllReduce");
+    }
+    g_allreduce = (nccl_allreduce_fn) sym;
+    g_nccl_errstr = (nccl_errstr_fn) (lib ? dlsym(lib, "ncclGetErrorString") : dlsym(RTLD_DEFAULT, "ncclGetErrorString"));
+}
+} // namespace
+
+extern "C" int hf_allreduce_grad(float *d_grad, size_t count, void *rccl_comm, hf_stream_t stream) {
+    if (!d_grad || !rccl_comm) return fail(HF_EINVAL, "hf_allreduce_grad: NULL argument");
+    if (count == 0) return HF_OK;
+    std::call_once(g_nccl_once, bind_rccl);
+    if (!g_allreduce) return fail(HF_EDEVICE, "hf_allreduce_grad: RCCL (ncclAllReduce) not found in the process or as librccl.so");
+    // ncclFloat32 = 7, ncclSum = 0 (rccl.h: ncclDataType_t / ncclRedOp_t)
+    const int rc = g_allreduce(d_grad, d_grad, count, 7, 0, rccl_comm, (hipStream_t) stream);
+    if (rc != 0)
+        return fail(HF_EDEVICE, "hf_allreduce_grad: ncclAllReduce failed: %s", g_nccl_errstr ? g_nccl_errstr(rc) : "error");
     return HF_OK;
 }

@@ -382,6 +382,54 @@ class Heightfield:
         check(_capi.lib().hf_ray_test(self._h, n, C.byref(rays), ap, hit.data_ptr(), self._stream()))
         return hit.bool()
 
+    # ---- scalar / packet forms (shape.h:220-240): host arrays in, host arrays out -------------------
+    def ray_intersect_preliminary_packet(self, o, d, maxt=None, active=None):
+        """``ray_intersect_preliminary_packet`` / ``_scalar`` (shape.h:220-240, the per-kd-leaf call of
+        kdtree.h:2490-2520): up to 16 rays held in HOST memory (numpy / CPU tensors, [3, n] or [3]).  Returns
+        host arrays ``(t, prim_uv [2, n], prim_index)``.  Same kernel and arithmetic as the wavefront entry,
+        one synchronous launch per call (``hf_ray_intersect_preliminary_packet``)."""
+        import numpy as np
+        o, d, maxt, act, n = self._host_packet(o, d, maxt, active)
+        t = np.empty(n, np.float32); uv = np.empty((2, n), np.float32); prim = np.empty(n, np.uint32)
+        op, dp = self._host_rows(o), self._host_rows(d)
+        uvp = (C.c_void_p * 2)(uv[0].ctypes.data, uv[1].ctypes.data)
+        check(_capi.lib().hf_ray_intersect_preliminary_packet(self._h, n, C.byref(op), C.byref(dp), maxt.ctypes.data,
+                                                              act.ctypes.data if act is not None else None,
+                                                              t.ctypes.data, C.byref(uvp), prim.ctypes.data))
+        return t, uv, prim
+
+    def ray_intersect_preliminary_scalar(self, o, d, maxt=math.inf):
+        t, uv, prim = self.ray_intersect_preliminary_packet(o, d, maxt)
+        return float(t[0]), (float(uv[0, 0]), float(uv[1, 0])), int(prim[0])
+
+    def ray_test_packet(self, o, d, maxt=None, active=None):
+        import numpy as np
+        o, d, maxt, act, n = self._host_packet(o, d, maxt, active)
+        hit = np.empty(n, np.uint8)
+        op, dp = self._host_rows(o), self._host_rows(d)
+        check(_capi.lib().hf_ray_test_packet(self._h, n, C.byref(op), C.byref(dp), maxt.ctypes.data,
+                                             act.ctypes.data if act is not None else None, hit.ctypes.data))
+        return hit.astype(bool)
+
+    def ray_test_scalar(self, o, d, maxt=math.inf):
+        return bool(self.ray_test_packet(o, d, maxt)[0])
+
+    @staticmethod
+    def _host_rows(a):
+        return (C.c_void_p * 3)(a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data)
+
+    @staticmethod
+    def _host_packet(o, d, maxt, active):
+        import numpy as np
+        o = np.ascontiguousarray(np.asarray(o, np.float32).reshape(3, -1))
+        d = np.ascontiguousarray(np.asarray(d, np.float32).reshape(3, -1))
+        n = max(o.shape[1], d.shape[1])
+        o = np.ascontiguousarray(np.broadcast_to(o, (3, n))); d = np.ascontiguousarray(np.broadcast_to(d, (3, n)))
+        maxt = np.full(n, math.inf, np.float32) if maxt is None else \
+            np.ascontiguousarray(np.broadcast_to(np.asarray(maxt, np.float32).reshape(-1), (n,)))
+        act = None if active is None else np.ascontiguousarray(np.broadcast_to(np.asarray(active).astype(np.uint8).reshape(-1), (n,)))
+        return o, d, maxt, act, n
+
     def _package_si(self, ray, pi_t, pi_prim, diff, aux, ray_flags):
         n = len(ray)
         si = SurfaceInteraction3f()

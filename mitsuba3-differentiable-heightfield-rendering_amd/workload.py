@@ -54,12 +54,35 @@ def tea32(v0, v1, rounds=4):
     return v0, v1
 
 
+def partition_tiles(film_w, film_h, world, tile=32):
+    """Image-tile partition of one wavefront over `world` ranks (BASELINE configs[3]: "pixel-tiled across
+    8xMI355X"): the film is cut into tile x tile pixel blocks (MI_BLOCK_SIZE = 32, src/render/integrator.cpp:
+    130-140) in row-major block order and block b goes to rank b % world -- interleaved, so every rank sees the
+    same mix of empty and expensive image regions.  Returns one int64 tensor of pixel indices (y * film_w + x,
+    the wavefront's index>>log2(spp) of integrator.cpp:251-268) per rank, block after block, row-major inside
+    a block; the lists are disjoint and cover the film (tests/test_partition.py)."""
+    bx, by = (film_w + tile - 1) // tile, (film_h + tile - 1) // tile
+    yy, xx = torch.meshgrid(torch.arange(film_h), torch.arange(film_w), indexing="ij")
+    block = (yy // tile) * bx + (xx // tile)                       # block id of every pixel
+    pix = (yy * film_w + xx).reshape(-1)
+    block = block.reshape(-1)
+    # stable sort by (block, then row-major inside the block): pixel order within a rank's list
+    order = torch.argsort(block * (tile * tile) + ((yy % tile) * tile + (xx % tile)).reshape(-1), stable=True)
+    pix, block = pix[order], block[order]
+    return [pix[(block % world) == r].contiguous() for r in range(world)]
+
+
 def ortho_rays(film_w, film_h, spp, device, start=0, count=None, seed=0,
                origin=(1.5, 1.5, 1.5), target=(0.0, 0.0, 0.125), up=(0.0, 0.0, 1.0),
-               scale=(1.6, 1.6, 1.0), near=1e-2, far=1e4, chunk=1 << 24):
+               scale=(1.6, 1.6, 1.0), near=1e-2, far=1e4, chunk=1 << 24, pixels=None):
     """Rays [start, start+count) of the W*H*spp wavefront as a [7, count] float32 tensor
-    (ox,oy,oz,dx,dy,dz,maxt)."""
+    (ox,oy,oz,dx,dy,dz,maxt).  With `pixels` (int64 tensor of pixel indices, e.g. one rank's list from
+    partition_tiles) the result is instead the spp samples of exactly those pixels, pixel after pixel: ray
+    k*spp + s is wavefront index pixels[k]*spp + s -- the same rays, bit for bit, as in the full wavefront."""
     total = film_w * film_h * spp
+    if pixels is not None:
+        pixels = pixels.to(device=device, dtype=torch.int64)
+        start, count = 0, int(pixels.numel()) * spp
     count = total - start if count is None else count
     to_world = look_at(origin, target, up) @ np.diag([scale[0], scale[1], scale[2], 1.0])
     tw = torch.tensor(to_world, dtype=torch.float64, device=device)
@@ -70,6 +93,8 @@ def ortho_rays(film_w, film_h, spp, device, start=0, count=None, seed=0,
     for c0 in range(0, count, chunk):
         c1 = min(count, c0 + chunk)
         idx = torch.arange(start + c0, start + c1, dtype=torch.int64, device=device)
+        if pixels is not None:   # local index -> index in the full wavefront
+            idx = pixels[idx // spp] * spp + idx % spp
         v0, v1 = tea32(torch.full_like(idx, seed), idx)
         jx = (v0 >> 9).to(torch.float64) * (1.0 / (1 << 23))
         jy = (v1 >> 9).to(torch.float64) * (1.0 / (1 << 23))
