@@ -438,8 +438,23 @@ class Heightfield:
         sh_n = diff[9:12]
         si.dp_du, si.dp_dv = diff[12:15], diff[15:18]
         si.boundary_test = aux[0] if (ray_flags & RayFlags.BoundaryTest) else torch.zeros(n, device=self.device)
-        si.sh_frame = Frame3f(aux[1:4], aux[4:7], sh_n)
-        si.wi = aux[7:10]
+        sh_s, sh_t, wi = aux[1:4], aux[4:7], aux[7:10]
+        if diff.requires_grad and (ray_flags & RayFlags.ShadingFrame):
+            # finalize_surface_interaction is AD-attached in the reference (interaction.h:257-267, 476-499):
+            # sh_frame.s = normalize(dp_du - n <n, dp_du>), t = cross(n, s), wi = to_local(-d).  The kernel's rows are
+            # plain outputs, so when gradients are wanted these three are rebuilt here from the differentiable rows
+            # (sh_frame.n, dp_du, ray.d): a BSDF that reads cos_theta = wi.z then back-propagates to the heights.
+            dp_du = si.dp_du
+            s_un = dp_du - sh_n * (sh_n * dp_du).sum(0, keepdim=True)
+            nrm = torch.linalg.norm(s_un, dim=0, keepdim=True)
+            ok = (nrm > 0) & torch.isfinite(diff[0])[None, :]
+            s_at = s_un / torch.where(ok, nrm, torch.ones_like(nrm))
+            sh_s = torch.where(ok, s_at, aux[1:4])           # degenerate dp_du / misses: the kernel's (detached) rows
+            sh_t = torch.where(ok, torch.linalg.cross(sh_n, sh_s, dim=0), aux[4:7])
+            md = -ray.d
+            wi = torch.where(ok, torch.stack([(md * sh_s).sum(0), (md * sh_t).sum(0), (md * sh_n).sum(0)]), aux[7:10])
+        si.sh_frame = Frame3f(sh_s, sh_t, sh_n)
+        si.wi = wi
         zeros3 = torch.zeros((3, n), dtype=torch.float32, device=self.device)
         si.dn_du, si.dn_dv = zeros3, zeros3          # flat shading
         si.duv_dx = si.duv_dy = torch.zeros((2, n), dtype=torch.float32, device=self.device)

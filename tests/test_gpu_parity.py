@@ -183,3 +183,43 @@ def test_error_behaviour(hf):
     # NaN / inf rays are misses, not hangs
     bad = hf.Ray3f(torch.tensor([[float("nan")], [0.0], [2.0]]).cuda(), torch.tensor([[0.0], [float("inf")], [-1.0]]).cuda())
     assert not f.ray_intersect_preliminary(bad).is_valid().any()
+
+
+def test_wi_and_shading_frame_carry_gradients(hf, oracle):
+    """finalize_surface_interaction is AD-attached in the reference (interaction.h:257-267, 476-499): a loss on
+    si.wi.z = <-d, sh_frame.n> must reach the heights and the ray direction.  d(sum wi.z)/dh equals the explicit
+    adjoint with upstream dL/dsh_n = -d; d(wi.z)/dd = -sh_n (+ the path through the hit point)."""
+    rng = np.random.default_rng(17)
+    h = common.heights("sine", 48, 40, rng)
+    f_o, f_g = _mk(hf, oracle, h)
+    r = common.random_rays(6000, rng)
+    f_g.heightfield.requires_grad_(True)
+    rt = torch.from_numpy(r).cuda()
+    d = rt[3:6].contiguous().requires_grad_(True)
+    ray = hf.Ray3f(rt[0:3].contiguous(), d, rt[6].contiguous())
+    si = f_g.ray_intersect(ray, hf.RayFlags.All)
+    hit = si.is_valid()
+    assert float(hit.float().mean()) > 0.2
+    # primal: the rebuilt rows agree with the kernel's own
+    pi = f_g.ray_intersect_preliminary(ray)
+    with torch.no_grad():
+        si_k = f_g.compute_surface_interaction(hf.Ray3f(rt[0:3].contiguous(), rt[3:6].contiguous(), rt[6].contiguous()), pi)
+    assert torch.allclose(si.wi[:, hit], si_k.wi[:, hit], rtol=1e-5, atol=1e-6)
+    assert torch.allclose(si.sh_frame.s[:, hit], si_k.sh_frame.s[:, hit], rtol=1e-5, atol=1e-6)
+    assert torch.allclose(si.sh_frame.t[:, hit], si_k.sh_frame.t[:, hit], rtol=1e-5, atol=1e-6)
+    si.wi[2][hit].sum().backward()
+    g_auto = f_g.heightfield.grad.clone()
+    assert float(g_auto.abs().max()) > 0
+    g = torch.zeros((18, r.shape[1]), device="cuda")
+    g[9:12] = -rt[3:6] * hit                      # dL/dsh_n = -d on the hit lanes
+    g_exp = f_g.adjoint(hf.Ray3f(rt[0:3].contiguous(), rt[3:6].contiguous(), rt[6].contiguous()), pi, g)
+    err = float(torch.linalg.norm((g_auto - g_exp).double()) / torch.linalg.norm(g_exp.double()))
+    assert err < 1e-5, err
+    # explicit dependence on the direction: -sh_n, plus what flows through sh_n(p(d)) = 0 for flat triangles
+    gd = d.grad[:, hit]
+    assert torch.allclose(gd, -si.sh_frame.n.detach()[:, hit], rtol=1e-4, atol=1e-5)
+    # the tangent frame is differentiable too: a loss on sh_frame.s reaches the heights
+    f_g.heightfield.grad = None
+    si2 = f_g.ray_intersect(hf.Ray3f(rt[0:3].contiguous(), rt[3:6].contiguous(), rt[6].contiguous()), hf.RayFlags.All)
+    si2.sh_frame.s[2][hit].sum().backward()
+    assert float(f_g.heightfield.grad.abs().max()) > 0
