@@ -311,6 +311,20 @@ def other_launches(torch, hf_amd, _capi, lib, shape, r_s, pi_s, si_s, si, R, str
         e1.record(); torch.cuda.synchronize()
         out[name] = round(e0.elapsed_time(e1) / iters, 4)
     out["secondary_rays"] = int(Rs)
+    # BASELINE configs[4] stand-in (examples/inverse_heights.py): 100 Adam steps, loss = multi-light renders only,
+    # end-to-end wall-clock on this GPU (trace -> shade -> loss -> adjoints -> hf_adam_step incl. rebuild)
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "examples"))
+        import inverse_heights
+        inverse_heights.run(grid=64, film=64, spp=1, steps=3, verbose=False)            # code objects, allocator
+        hist, err, wall = inverse_heights.run(grid=1024, film=512, spp=16, steps=100, lr=0.04, verbose=False)
+        out["configs4_inverse_loop"] = {"grid": 1024, "rays_per_step": 512 * 512 * 16, "adam_steps": 100,
+                                        "wall_clock_s": round(wall, 4), "loss_first": round(hist[0], 6),
+                                        "loss_last": round(hist[-1], 6),
+                                        "centred_height_error_first": round(inverse_heights.run.start_centred_error, 5),
+                                        "centred_height_error_last": round(inverse_heights.run.last_centred_error, 5)}
+    except Exception as e:   # the headline number must not depend on the example
+        out["configs4_inverse_loop"] = {"error": repr(e)}
     return out
 
 

@@ -11,7 +11,7 @@
 
 #include "hf_launch.h"
 
-#define HF_NUM_COUNTERS 256
+#define HF_NUM_SLOTS 64
 struct hf_field {
     hf_dev_field dev;   // device view handed to kernels by value
     float *d_heights;   // owned copy of the heights
@@ -20,13 +20,15 @@ struct hf_field {
     size_t mip_nodes;
     int device;
     hipEvent_t built;   // completion of the last hf_set_heights*
-    // Ring of work counters, one slot per in-flight trace launch.  Every slot carries the completion event of
-    // the launch that used it last: a launch that re-uses the slot first makes its stream wait for that event
-    // (a device-side wait, normally long past), so two pending launches never share or reset a counter, and
-    // hf_destroy waits for exactly the launches of this handle instead of the whole device.
-    unsigned long long *d_counters;
-    hipEvent_t slot_done[HF_NUM_COUNTERS];
-    bool slot_used[HF_NUM_COUNTERS];
+    // Ring of scratch blocks (the work counters of a launch), one slot per in-flight trace launch.  Every slot
+    // carries the completion event of the launch that used it last: a launch that re-uses the slot first makes
+    // its stream wait for that event (a device-side wait, normally long past), so two pending launches never
+    // share a block, and hf_destroy waits for exactly the launches of this handle instead of the whole device.
+    // Blocks are allocated on first use (hf_trace_scratch_bytes).
+    char *slot_buf[HF_NUM_SLOTS];
+    size_t slot_cap[HF_NUM_SLOTS];
+    hipEvent_t slot_done[HF_NUM_SLOTS];
+    bool slot_used[HF_NUM_SLOTS];
     uint32_t next_slot;
     std::mutex *slot_mutex;
 };
@@ -46,14 +48,24 @@ struct hf_device_guard {
     ~hf_device_guard() { if (prev >= 0) (void) hipSetDevice(prev); }
 };
 
-// claims the next counter slot for a launch on `stream`; *slot receives the slot number for slot_release
-static unsigned long long *slot_acquire(const hf_field *hf, hipStream_t stream, uint32_t *slot) {
+// claims the next scratch slot for a launch on `stream` with at least `bytes` of scratch; *slot receives the slot
+// number for slot_release.  NULL when the block cannot be allocated.
+static void *slot_acquire(const hf_field *hf, hipStream_t stream, size_t bytes, uint32_t *slot) {
     hf_field *m = const_cast<hf_field *>(hf);
     std::lock_guard<std::mutex> lock(*m->slot_mutex);
-    const uint32_t k = m->next_slot++ % HF_NUM_COUNTERS;
-    if (m->slot_used[k]) (void) hipStreamWaitEvent(stream, m->slot_done[k], 0);
+    const uint32_t k = m->next_slot++ % HF_NUM_SLOTS;
     *slot = k;
-    return m->d_counters + (size_t) k * HF_COUNTERS_PER_LAUNCH;
+    if (m->slot_cap[k] < bytes) { // grow: the previous user must be done before its block goes away
+        if (m->slot_used[k]) (void) hipEventSynchronize(m->slot_done[k]);
+        if (m->slot_buf[k]) (void) hipFree(m->slot_buf[k]);
+        m->slot_buf[k] = nullptr; m->slot_cap[k] = 0;
+        size_t cap = bytes < 65536 ? 65536 : bytes + bytes / 2;
+        if (hipMalloc((void **) &m->slot_buf[k], cap) != hipSuccess) return nullptr;
+        m->slot_cap[k] = cap;
+    } else if (m->slot_used[k]) {
+        (void) hipStreamWaitEvent(stream, m->slot_done[k], 0);
+    }
+    return m->slot_buf[k];
 }
 static void slot_release(const hf_field *hf, hipStream_t stream, uint32_t slot) {
     hf_field *m = const_cast<hf_field *>(hf);
@@ -124,12 +136,13 @@ static int set_transform(hf_field *hf, const float *to_world, const float *to_ob
 // frees whatever a (possibly half-constructed) handle owns
 static void release(hf_field *hf) {
     if (hf->built) (void) hipEventDestroy(hf->built);
-    for (int k = 0; k < HF_NUM_COUNTERS; ++k)
+    for (int k = 0; k < HF_NUM_SLOTS; ++k) {
         if (hf->slot_done[k]) (void) hipEventDestroy(hf->slot_done[k]);
+        if (hf->slot_buf[k]) (void) hipFree(hf->slot_buf[k]);
+    }
     if (hf->d_heights) (void) hipFree(hf->d_heights);
     if (hf->d_mip) (void) hipFree(hf->d_mip);
     if (hf->d_shear) (void) hipFree(hf->d_shear);
-    if (hf->d_counters) (void) hipFree(hf->d_counters);
     delete hf->slot_mutex;
     free(hf);
 }
@@ -176,9 +189,8 @@ extern "C" int hf_create(const hf_desc_t *desc, hf_field_t **out) {
     hipError_t e = hipMalloc((void **) &hf->d_heights, sizeof(float) * (size_t) d.W * d.H);
     if (e == hipSuccess) e = hipMalloc((void **) &hf->d_mip, sizeof(float2) * off);
     if (e == hipSuccess) e = hipMalloc((void **) &hf->d_shear, sizeof(float4) * 3 * (hf_shear_records(top) + 1));
-    if (e == hipSuccess) e = hipMalloc((void **) &hf->d_counters, sizeof(unsigned long long) * HF_COUNTERS_PER_LAUNCH * HF_NUM_COUNTERS);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&hf->built, hipEventDisableTiming);
-    for (int k = 0; k < HF_NUM_COUNTERS && e == hipSuccess; ++k)
+    for (int k = 0; k < HF_NUM_SLOTS && e == hipSuccess; ++k)
         e = hipEventCreateWithFlags(&hf->slot_done[k], hipEventDisableTiming);
     hf->slot_mutex = new (std::nothrow) std::mutex();
     if (e == hipSuccess && !hf->slot_mutex) e = hipErrorOutOfMemory;
@@ -207,7 +219,7 @@ extern "C" int hf_destroy(hf_field_t *hf) {
     // wait for the work of THIS handle only (its last rebuild and the launches still holding a counter slot);
     // other streams of the host application keep running
     (void) hipEventSynchronize(hf->built);
-    for (int k = 0; k < HF_NUM_COUNTERS; ++k)
+    for (int k = 0; k < HF_NUM_SLOTS; ++k)
         if (hf->slot_used[k]) (void) hipEventSynchronize(hf->slot_done[k]);
     release(hf);
     return HF_OK;
@@ -357,7 +369,8 @@ extern "C" int hf_ray_intersect_preliminary(const hf_field_t *hf, size_t n, cons
     if (!out || (n && !out->t)) return fail(HF_EINVAL, "hf_ray_intersect_preliminary: NULL output");
     {
         uint32_t slot;
-        unsigned long long *counter = slot_acquire(hf, (hipStream_t) stream, &slot);
+        void *counter = slot_acquire(hf, (hipStream_t) stream, hf_trace_scratch_bytes(n), &slot);
+        if (!counter) return fail(HF_ENOMEM, "trace launch: scratch allocation failed");
         hf_launch_trace(0, hf->dev, n, rays, active, out, nullptr, nullptr, 0, counter, (hipStream_t) stream);
         slot_release(hf, (hipStream_t) stream, slot);
     }
@@ -372,7 +385,8 @@ extern "C" int hf_ray_test(const hf_field_t *hf, size_t n, const hf_rays_t *rays
     if (n && !out_hit) return fail(HF_EINVAL, "hf_ray_test: NULL output");
     {
         uint32_t slot;
-        unsigned long long *counter = slot_acquire(hf, (hipStream_t) stream, &slot);
+        void *counter = slot_acquire(hf, (hipStream_t) stream, hf_trace_scratch_bytes(n), &slot);
+        if (!counter) return fail(HF_ENOMEM, "trace launch: scratch allocation failed");
         hf_launch_trace(1, hf->dev, n, rays, active, nullptr, out_hit, nullptr, 0, counter, (hipStream_t) stream);
         slot_release(hf, (hipStream_t) stream, slot);
     }
@@ -402,7 +416,8 @@ extern "C" int hf_ray_intersect(const hf_field_t *hf, size_t n, const hf_rays_t 
     if (!out_si) return fail(HF_EINVAL, "hf_ray_intersect: NULL output");
     {
         uint32_t slot;
-        unsigned long long *counter = slot_acquire(hf, (hipStream_t) stream, &slot);
+        void *counter = slot_acquire(hf, (hipStream_t) stream, hf_trace_scratch_bytes(n), &slot);
+        if (!counter) return fail(HF_ENOMEM, "trace launch: scratch allocation failed");
         hf_launch_trace(2, hf->dev, n, rays, active, out_pi, nullptr, out_si, ray_flags, counter, (hipStream_t) stream);
         slot_release(hf, (hipStream_t) stream, slot);
     }
@@ -594,7 +609,8 @@ int packet_trace(const char *fn, int mode, const hf_field_t *hf, uint32_t n, con
     pi.prim_index = (uint32_t *) (d32 + 10 * HF_PACKET_MAX);
     {
         uint32_t slot;
-        unsigned long long *counter = slot_acquire(hf, st->stream, &slot);
+        void *counter = slot_acquire(hf, st->stream, hf_trace_scratch_bytes(n), &slot);
+        if (!counter) return fail(HF_ENOMEM, "%s: scratch allocation failed", fn);
         hf_launch_trace(mode, hf->dev, n, &rays, dmask, mode == 0 ? &pi : nullptr, mode == 1 ? dhit : nullptr, nullptr, 0,
                         counter, st->stream);
         slot_release(hf, st->stream, slot);

@@ -185,9 +185,38 @@ struct hf_si_rec {
 
 __device__ __forceinline__ float clamp01(float x) { return fminf(fmaxf(x, 0.f), 1.f); }
 
-// flat-shaded boundary test = SDF of the hit point in an equilateral reference triangle
-// (src/render/mesh.cpp:845-890)
-__device__ __forceinline__ float boundary_test_flat(v3 p, v3 p0, v3 dp0, v3 dp1) {
+// Which of the hit triangle's three edges (k = 0: P0-P1, 1: P1-P2, 2: P2-P0) are SILHOUETTE edges for a ray of
+// object-space direction od: the neighbour across the edge does not exist (border of the grid) or faces the ray
+// the other way.  A grid triangle with slopes (zx, zy) faces the ray by sign(od.z - zx od.x - zy od.y).  Interior
+// edges between triangles that face the ray the same way are no visibility boundary.
+__device__ __forceinline__ bool tri_faces(float zx, float zy, v3 od) {
+    return __builtin_fmaf(-zy, od.y, __builtin_fmaf(-zx, od.x, od.z)) >= 0.f;
+}
+__device__ __forceinline__ uint32_t silhouette_edges(const hf_dev_field &f, uint32_t prim, v3 od) {
+    const uint32_t cw = (uint32_t) (f.W - 1);
+    const int cy = (int) ((prim >> 1) / cw), cx = (int) ((prim >> 1) - (uint32_t) cy * cw);
+    const float s = f.s, isx = 1.0f / f.sx, isy = 1.0f / f.sy;
+    auto hz = [&](int i, int j) { return f.h[(size_t) i * f.W + j] * s; };
+    const float z00 = hz(cy, cx), z10 = hz(cy, cx + 1), z01 = hz(cy + 1, cx), z11 = hz(cy + 1, cx + 1);
+    const bool f0 = tri_faces((z10 - z00) * isx, (z01 - z00) * isy, od); // tri 0 = (v00, v10, v01)
+    const bool f1 = tri_faces((z11 - z01) * isx, (z11 - z10) * isy, od); // tri 1 = (v11, v01, v10)
+    uint32_t m = 0;
+    if ((prim & 1u) == 0) {
+        if (cy == 0 || tri_faces((z10 - z00) * isx, (z10 - hz(cy - 1, cx + 1)) * isy, od) != f0) m |= 1u; // bottom
+        if (f1 != f0) m |= 2u;                                                                             // diagonal
+        if (cx == 0 || tri_faces((z01 - hz(cy + 1, cx - 1)) * isx, (z01 - z00) * isy, od) != f0) m |= 4u; // left
+    } else {
+        if (cy + 2 > f.H - 1 || tri_faces((z11 - z01) * isx, (hz(cy + 2, cx) - z01) * isy, od) != f1) m |= 1u; // top
+        if (f0 != f1) m |= 2u;
+        if (cx + 2 > f.W - 1 || tri_faces((hz(cy, cx + 2) - z10) * isx, (z11 - z10) * isy, od) != f1) m |= 4u; // right
+    }
+    return m;
+}
+
+// boundary test of the height field = the SDF of the hit point in an equilateral reference triangle
+// (src/render/mesh.cpp:845-890), restricted to the silhouette edges; 1 (the incentre value) when there is none
+__device__ __forceinline__ float boundary_test_flat(v3 p, v3 p0, v3 dp0, v3 dp1, uint32_t edges) {
+    if (edges == 0u) return 1.0f;
     const v3 rel = p - p0;
     const float bb1 = dot3(dp0, rel), bb2 = dot3(dp1, rel);
     const float a11 = dot3(dp0, dp0), a12 = dot3(dp0, dp1), a22 = dot3(dp1, dp1);
@@ -201,6 +230,7 @@ __device__ __forceinline__ float boundary_test_flat(v3 p, v3 p0, v3 dp0, v3 dp1)
     float dmin = __builtin_inff();
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
+        if (!((edges >> k) & 1u)) continue;
         const int k1 = (k + 1) % 3;
         const float ex = tpx[k1] - tpx[k], ey = tpy[k1] - tpy[k];
         const float vx = qx - tpx[k], vy = qy - tpy[k];
@@ -267,7 +297,9 @@ __device__ __forceinline__ void compute_si(const hf_dev_field &f, v3 o, v3 d, fl
     }
     si.sh_n = si.n;
     if (f.flip) { si.n = neg3(si.n); si.sh_n = neg3(si.sh_n); }
-    si.boundary_test = (flags & 0x40u) ? boundary_test_flat(si.p, P[0], dp0, dp1) : 0.f;
+    si.boundary_test = 0.f;
+    if (flags & 0x40u)
+        si.boundary_test = boundary_test_flat(si.p, P[0], dp0, dp1, silhouette_edges(f, prim, xform_vec(f.to_object, d)));
     si.sh_s = mk3(0.f, 0.f, 0.f); si.sh_t = mk3(0.f, 0.f, 0.f);
     if (flags & 0x8u) { // initialize_sh_frame: Gram-Schmidt on dp_du
         const float nd = -dot3(si.sh_n, si.dp_du);

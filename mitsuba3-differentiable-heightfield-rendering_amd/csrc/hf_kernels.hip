@@ -396,86 +396,115 @@ struct hf_src_global {
 // "while-while": each lane walks until it holds a block with candidate cells (or is done); when
 // every lane of the call has stopped, the candidate cells are triangle-tested together, one
 // cell per lane per round -- the expensive test runs with all waiting lanes active.
+struct hf_walk {
+    uint32_t X, Y, cur, pend; // node (X,Y) of level L, its order-space children still to visit; candidate cells
+    uint64_t stk;             // 4 bits per level: the ancestors' pending children (L0 can be the root of a 2^15-cell grid)
+    int L, pc0, pr0;          // level; actual lower-left cell of the parked block
+    float pfx, pfy;           // order-space origin of the parked block
+    bool fin, pblk;           // subtree exhausted / parked on a level-1 node
+};
+// start one level above the subtree root: a virtual parent whose only pending child is the root
+__device__ __forceinline__ void walk_init(hf_walk &w, uint32_t X0, uint32_t Y0, int L0) {
+    w.X = X0 >> 1; w.Y = Y0 >> 1; w.cur = 1u << ((X0 & 1u) | ((Y0 & 1u) << 1)); w.pend = 0u;
+    w.stk = 0ull; w.L = L0 + 1; w.pc0 = 0; w.pr0 = 0; w.pfx = 0.f; w.pfy = 0.f; w.fin = false; w.pblk = false;
+}
+__device__ __forceinline__ void walk_idle(hf_walk &w) {
+    w.X = 0u; w.Y = 0u; w.cur = 0u; w.pend = 0u; w.stk = 0ull; w.L = 0; w.pc0 = 0; w.pr0 = 0; w.pfx = 0.f; w.pfy = 0.f;
+    w.fin = true; w.pblk = false;
+}
+
+// One round of the walk for every lane of the call: walk until parked or done, then the parked blocks, then
+// the candidate cells.  Lanes with w.fin set do nothing.  Returns whether this lane recorded a hit.
 template <bool ANY, typename Src>
-__device__ __forceinline__ bool walk_subtree(const hf_dev_field &f, const Src &src, const hf_ray_state &rs,
-                                             const hf_trav &r, bool fx, bool fy, uint32_t fxm, uint32_t fym,
-                                             uint32_t X0, uint32_t Y0, int L0, float &thi, hf_hit &best
-) {
+__device__ __forceinline__ bool walk_round(const hf_dev_field &f, const Src &src, const hf_ray_state &rs,
+                                           const hf_trav &r, bool fx, bool fy, uint32_t fxm, uint32_t fym,
+                                           float &thi, hf_hit &best, hf_walk &w) {
     auto loadh = [&src](int i, int j) { return src.height(i, j); };
-    bool hit_any = false, fin = false, pblk = false;
-    // start one level above the subtree root: a virtual parent whose only pending child is the root
-    uint32_t X = X0 >> 1, Y = Y0 >> 1, cur = 1u << ((X0 & 1u) | ((Y0 & 1u) << 1)), pend = 0;
-    uint64_t stk = 0; // 4 bits per level from L0 down; L0 can be the root of a 2^15-cell grid (incoherent waves)
-    int L = L0 + 1, pc0 = 0, pr0 = 0;
-    float pfx = 0.f, pfy = 0.f; // order-space origin of the parked block
-    for (;;) {
-        // ---- walk until this lane reaches a level-1 node (parks on it) or has exhausted the subtree ----
-        while (!fin && !pblk) {
-            WCOUNT(3);
-            while (cur == 0u && L <= L0) { // node exhausted: pop
-                cur = (uint32_t) stk & 15u; stk >>= 4;
-                X >>= 1; Y >>= 1; ++L;
-            }
-            if (cur == 0u) { fin = true; break; }
-            const uint32_t k = (uint32_t) __builtin_ctz(cur);
-            cur &= cur - 1u;
-            const uint32_t cx = 2u * X + (k & 1u), cy = 2u * Y + (k >> 1);
-            const float S = (float) (1u << (L - 1));
-            // the mask may predate a hit: re-check the child's entry against the current t_hi
-            const float te = fmaxf(((float) cx * S - r.gxm) * r.idx, ((float) cy * S - r.gym) * r.idy);
-            if (te > thi) continue;
-            if (L == 2) { // child is a level-1 node: park, its 2x2 cells are examined wave-converged below
-                pc0 = (int) (2u * (cx ^ (fxm >> 1))); pr0 = (int) (2u * (cy ^ (fym >> 1)));
-                pfx = (float) (2u * cx); pfy = (float) (2u * cy);
-                pblk = true;
-                continue;
-            }
-            WCOUNT(5);
-            stk = (stk << 4) | (uint64_t) cur;
-            X = cx; Y = cy; --L;
-            // the four children of (X,Y,L): sheared bounds on the fine levels, min/max boxes above
-            const float Sc = 0.5f * S;
-            const uint32_t ix = X ^ (fxm >> L), iy = Y ^ (fym >> L);
-            hf_quad q;
-            float gz, dz, mz;
-            {   // A wave-level gather returns when its slowest lane does (an L2 / Infinity Cache round trip, not an
-                // L1 hit), so the plane and the child ranges of the record are requested together: one memory round
-                // trip per visit.  Levels above HF_SHEAR_TOP carry the zero plane (hf_shear_minmax_kernel).
-                const float4 *rec = src.sheared(L, ix, iy);
-                const float4 pl = rec[0], q01 = rec[1], q23 = rec[2];
-                shear_line(f, rs, fx, fy, pl.x, pl.y, pl.z, pl.w, __builtin_fmaf((float) X, S, Sc),
-                           __builtin_fmaf((float) Y, S, Sc), gz, dz, mz);
-                q.lo[0] = q01.x; q.hi[0] = q01.y; q.lo[1] = q01.z; q.hi[1] = q01.w;
-                q.lo[2] = q23.x; q.hi[2] = q23.y; q.lo[3] = q23.z; q.hi[3] = q23.w;
-            }
-            cur = to_order(child_mask(r, fx, fy, (float) X * S, (float) Y * S, Sc, q, gz, dz, mz, thi), fx, fy);
+    bool hit_any = false;
+    // ---- walk until this lane reaches a level-1 node (parks on it) or has exhausted the subtree ----
+    while (!w.fin && !w.pblk) {
+        WCOUNT(3);
+        if (w.cur == 0u) {
+            // Node exhausted: pop.  Every level between here and the nearest ancestor with pending children is
+            // skipped at once (the masks are 4-bit fields of one register: count the empty ones); the virtual
+            // parent of the subtree root holds no children, so an all-zero stack means the subtree is done.
+            if (w.stk == 0ull) { w.fin = true; break; }
+            const uint32_t z = (uint32_t) __builtin_ctzll(w.stk) >> 2;
+            w.stk >>= 4u * z;
+            w.cur = (uint32_t) w.stk & 15u; w.stk >>= 4;
+            w.X >>= z + 1u; w.Y >>= z + 1u; w.L += (int) z + 1;
         }
-        if (__ballot(pblk) == 0ull) break; // every lane is done
-        // ---- parked blocks: 3x3 heights -> candidate cells, all parked lanes together ----
-        if (pblk) {
-            WCOUNT(4);
-            pend = block_cells(f, rs, fx, fy, pc0, pr0, pfx, pfy, thi, loadh);
-            pblk = false;
+        const uint32_t k = (uint32_t) __builtin_ctz(w.cur);
+        w.cur &= w.cur - 1u;
+        const uint32_t cx = 2u * w.X + (k & 1u), cy = 2u * w.Y + (k >> 1);
+        const float S = (float) (1u << (w.L - 1));
+        // the mask may predate a hit: re-check the child's entry against the current t_hi
+        const float te = fmaxf(((float) cx * S - r.gxm) * r.idx, ((float) cy * S - r.gym) * r.idy);
+        if (te > thi) continue;
+        if (w.L == 2) { // child is a level-1 node: park, its 2x2 cells are examined wave-converged below
+            w.pc0 = (int) (2u * (cx ^ (fxm >> 1))); w.pr0 = (int) (2u * (cy ^ (fym >> 1)));
+            w.pfx = (float) (2u * cx); w.pfy = (float) (2u * cy);
+            w.pblk = true;
+            continue;
         }
-        // ---- candidate cells, one per lane per round ----
-        while (__ballot(pend != 0u) != 0ull) {
-            WCOUNT(6);
-            if (pend != 0u) {
-                const int j = __builtin_ctz(pend);
-                pend &= pend - 1u;
-                const int cxx = pc0 + (j & 1), cyy = pr0 + (j >> 1);
-                const float z00 = loadh(cyy, cxx) * f.s, z10 = loadh(cyy, cxx + 1) * f.s;
-                const float z01 = loadh(cyy + 1, cxx) * f.s, z11 = loadh(cyy + 1, cxx + 1) * f.s;
-                if (test_cell(f, cxx, cyy, z00, z10, z01, z11, rs.oo, rs.od, rs.maxt, best)) {
-                    hit_any = true;
-                    float tb = best.t - rs.tin;
-                    tb = tb + __builtin_fabsf(tb) * 1e-6f + 1e-30f;
-                    thi = fminf(thi, tb);
-                    if (ANY) { pend = 0u; fin = true; }
-                }
+        WCOUNT(5);
+        w.stk = (w.stk << 4) | (uint64_t) w.cur;
+        w.X = cx; w.Y = cy; --w.L;
+        // the four children of (X,Y,L): sheared bounds on the fine levels, min/max boxes above
+        const float Sc = 0.5f * S;
+        const uint32_t ix = w.X ^ (fxm >> w.L), iy = w.Y ^ (fym >> w.L);
+        hf_quad q;
+        float gz, dz, mz;
+        {   // A wave-level gather returns when its slowest lane does (an L2 / Infinity Cache round trip, not an
+            // L1 hit), so the plane and the child ranges of the record are requested together: one memory round
+            // trip per visit.  Levels above HF_SHEAR_TOP carry the zero plane (hf_shear_minmax_kernel).
+            const float4 *rec = src.sheared(w.L, ix, iy);
+            const float4 pl = rec[0], q01 = rec[1], q23 = rec[2];
+            shear_line(f, rs, fx, fy, pl.x, pl.y, pl.z, pl.w, __builtin_fmaf((float) w.X, S, Sc),
+                       __builtin_fmaf((float) w.Y, S, Sc), gz, dz, mz);
+            q.lo[0] = q01.x; q.hi[0] = q01.y; q.lo[1] = q01.z; q.hi[1] = q01.w;
+            q.lo[2] = q23.x; q.hi[2] = q23.y; q.lo[3] = q23.z; q.hi[3] = q23.w;
+        }
+        w.cur = to_order(child_mask(r, fx, fy, (float) w.X * S, (float) w.Y * S, Sc, q, gz, dz, mz, thi), fx, fy);
+    }
+    if (__ballot(w.pblk) == 0ull) return false; // nobody parked: every lane of the call is done
+    // ---- parked blocks: 3x3 heights -> candidate cells, all parked lanes together ----
+    if (w.pblk) {
+        WCOUNT(4);
+        w.pend = block_cells(f, rs, fx, fy, w.pc0, w.pr0, w.pfx, w.pfy, thi, loadh);
+        w.pblk = false;
+    }
+    // ---- candidate cells, one per lane per round ----
+    while (__ballot(w.pend != 0u) != 0ull) {
+        WCOUNT(6);
+        if (w.pend != 0u) {
+            const int j = __builtin_ctz(w.pend);
+            w.pend &= w.pend - 1u;
+            const int cxx = w.pc0 + (j & 1), cyy = w.pr0 + (j >> 1);
+            const float z00 = loadh(cyy, cxx) * f.s, z10 = loadh(cyy, cxx + 1) * f.s;
+            const float z01 = loadh(cyy + 1, cxx) * f.s, z11 = loadh(cyy + 1, cxx + 1) * f.s;
+            if (test_cell(f, cxx, cyy, z00, z10, z01, z11, rs.oo, rs.od, rs.maxt, best)) {
+                hit_any = true;
+                float tb = best.t - rs.tin;
+                tb = tb + __builtin_fabsf(tb) * 1e-6f + 1e-30f;
+                thi = fminf(thi, tb);
+                if (ANY) { w.pend = 0u; w.fin = true; }
             }
         }
     }
+    return hit_any;
+}
+
+template <bool ANY, typename Src>
+__device__ __forceinline__ bool walk_subtree(const hf_dev_field &f, const Src &src, const hf_ray_state &rs,
+                                             const hf_trav &r, bool fx, bool fy, uint32_t fxm, uint32_t fym,
+                                             uint32_t X0, uint32_t Y0, int L0, float &thi, hf_hit &best) {
+    hf_walk w;
+    walk_init(w, X0, Y0, L0);
+    bool hit_any = false;
+    do {
+        hit_any |= walk_round<ANY>(f, src, rs, r, fx, fy, fxm, fym, thi, best, w);
+    } while (__ballot(!w.fin) != 0ull);
     return hit_any;
 }
 
@@ -536,8 +565,7 @@ __device__ __forceinline__ void walk_packet(const hf_dev_field &f, const hf_lds_
             if (mine) {
                 // per-lane mirror flags: equal to (fx,fy) in a coherent wave, arbitrary otherwise
                 const uint32_t lfxm = rs.fx ? ((1u << top) - 1u) : 0u, lfym = rs.fy ? ((1u << top) - 1u) : 0u;
-                const bool h = walk_subtree<ANY>(f, src, rs, r, rs.fx, rs.fy, lfxm, lfym, cx, cy, L0, thi, best
-                );
+                const bool h = walk_subtree<ANY>(f, src, rs, r, rs.fx, rs.fy, lfxm, lfym, cx, cy, L0, thi, best);
                 if (ANY && h) thi = -1.f;
             }
 #ifdef HF_TSTATS
@@ -633,6 +661,8 @@ __device__ __forceinline__ void miss_si(hf_si_rec &si, v3 d, uint32_t flags) {
 }
 
 #define HF_GRAB 512 // most rays a wave takes from the work counter per fetch (hf_grab_for)
+// Scratch block of one trace launch (zeroed by hf_launch_trace): the per-XCD work counters.
+#define HF_SCR_BYTES 1024
 #ifndef HF_DIST
 #define HF_DIST 2
 #endif
@@ -896,11 +926,16 @@ static uint32_t hf_grab_for(size_t n) {
     return (uint32_t) g;
 }
 
+size_t hf_trace_scratch_bytes(size_t n) {
+    (void) n;
+    return HF_SCR_BYTES;
+}
+
 void hf_launch_trace(int mode, const hf_dev_field &f, size_t n, const hf_rays_t *rays, const uint8_t *active,
-                     const hf_pi_t *pi, uint8_t *hit, const hf_si_t *si, uint32_t flags, unsigned long long *counter,
+                     const hf_pi_t *pi, uint8_t *hit, const hf_si_t *si, uint32_t flags, void *scratch,
                      hipStream_t stream) {
     if (n == 0) return;
-    (void) hipMemsetAsync(counter, 0, sizeof(unsigned long long) * HF_NUM_XCD * HF_COUNTER_STRIDE, stream);
+    (void) hipMemsetAsync(scratch, 0, HF_SCR_BYTES, stream);
     hf_pi_dev p = { nullptr, nullptr, nullptr, nullptr };
     if (pi) { p.t = pi->t; p.u = pi->prim_uv[0]; p.v = pi->prim_uv[1]; p.prim = pi->prim_index; }
     hf_si_dev sd;
@@ -913,7 +948,7 @@ void hf_launch_trace(int mode, const hf_dev_field &f, size_t n, const hf_rays_t 
     const dim3 grid((unsigned) blocks), block(HF_BLOCK);
     hf_trace_args a;
     a.f = f; a.n = n; a.rays = r; a.active = active; a.pi = p; a.hit_out = hit; a.sio = sd; a.flags = flags;
-    a.counter = counter; a.grab = grab;
+    a.counter = (unsigned long long *) scratch; a.grab = grab;
     a.n_grabs = waves; a.band = (waves + HF_NUM_XCD - 1) / HF_NUM_XCD;
     if (mode == 0)
         hipLaunchKernelGGL(hf_trace_kernel<0>, grid, block, 0, stream, a);

@@ -6,11 +6,12 @@
 #include "hf_device.h"
 
 void hf_launch_build_mips(const hf_dev_field &f, float2 *mip, float4 *shear, hipStream_t stream);
-// counters a trace launch needs (zeroed by the launcher): one per XCD, 128 bytes apart
-#define HF_COUNTERS_PER_LAUNCH (8 * 16)
+// scratch block a trace launch needs (its work counters; the launcher zeroes it): hf_trace_scratch_bytes(n)
+// bytes, exclusively this launch's until it has completed
+size_t hf_trace_scratch_bytes(size_t n);
 // mode 0: closest hit -> pi; 1: any hit -> hit; 2: closest hit + fused surface interaction
 void hf_launch_trace(int mode, const hf_dev_field &f, size_t n, const hf_rays_t *rays, const uint8_t *active,
-                     const hf_pi_t *pi, uint8_t *hit, const hf_si_t *si, uint32_t flags, unsigned long long *counter,
+                     const hf_pi_t *pi, uint8_t *hit, const hf_si_t *si, uint32_t flags, void *scratch,
                      hipStream_t stream);
 void hf_launch_si(const hf_dev_field &f, size_t n, const hf_rays_t *rays, const hf_pi_const_t *pi,
                   const uint8_t *active, const hf_si_t *si, uint32_t flags, hipStream_t stream);

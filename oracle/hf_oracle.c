@@ -472,8 +472,46 @@ static void prim_world(const hfo_field *f, uint32_t prim, float P[3][3], float U
 
 static inline float clamp01(float x) { return fminf(fmaxf(x, 0.f), 1.f); }
 
-/* flat-shaded boundary test: triangle SDF, mesh.cpp:845-890 */
-static float boundary_test_flat(const float p[3], const float p0[3], const float dp0[3], const float dp1[3]) {
+/* Which of the hit triangle's three edges (k = 0: P0-P1, 1: P1-P2, 2: P2-P0) are SILHOUETTE edges for a ray of
+ * object-space direction od: the neighbour across the edge does not exist (border of the grid), or faces the
+ * ray the other way.  A triangle of the grid with slopes (zx, zy) faces the ray by sign(od.z - zx od.x - zy od.y)
+ * (its upward normal is (-zx, -zy, 1)).  Interior edges between two triangles that face the ray the same way are
+ * no visibility boundary, whatever the per-triangle SDF of mesh.cpp:863-890 says. */
+static inline int tri_faces(float zx, float zy, const float od[3]) { return fmaf(-zy, od[1], fmaf(-zx, od[0], od[2])) >= 0.f; }
+static uint32_t silhouette_edges(const hfo_field *f, uint32_t prim, const float od[3]) {
+    const uint32_t cw = (uint32_t) (f->W - 1);
+    const int cy = (int) ((prim >> 1) / cw), cx = (int) ((prim >> 1) - (uint32_t) cy * cw);
+    const float *h = f->h;
+    const float s = f->s, isx = 1.0f / f->sx, isy = 1.0f / f->sy;
+#define HZ(i, j) (h[(size_t) (i) * f->W + (j)] * s)
+    const float z00 = HZ(cy, cx), z10 = HZ(cy, cx + 1), z01 = HZ(cy + 1, cx), z11 = HZ(cy + 1, cx + 1);
+    const int f0 = tri_faces((z10 - z00) * isx, (z01 - z00) * isy, od);   /* tri 0 = (v00, v10, v01) */
+    const int f1 = tri_faces((z11 - z01) * isx, (z11 - z10) * isy, od);   /* tri 1 = (v11, v01, v10) */
+    uint32_t m = 0;
+    if ((prim & 1u) == 0) {
+        /* edge 0 = v00-v10 (bottom): tri 1 of cell (cx, cy-1) */
+        if (cy == 0 || tri_faces((z10 - z00) * isx, (z10 - HZ(cy - 1, cx + 1)) * isy, od) != f0) m |= 1u;
+        if (f1 != f0) m |= 2u;                                           /* edge 1 = the diagonal */
+        /* edge 2 = v01-v00 (left): tri 1 of cell (cx-1, cy) */
+        if (cx == 0 || tri_faces((z01 - HZ(cy + 1, cx - 1)) * isx, (z01 - z00) * isy, od) != f0) m |= 4u;
+    } else {
+        /* edge 0 = v11-v01 (top): tri 0 of cell (cx, cy+1) */
+        if (cy + 2 > f->H - 1 || tri_faces((z11 - z01) * isx, (HZ(cy + 2, cx) - z01) * isy, od) != f1) m |= 1u;
+        if (f0 != f1) m |= 2u;
+        /* edge 2 = v10-v11 (right): tri 0 of cell (cx+1, cy) */
+        if (cx + 2 > f->W - 1 || tri_faces((HZ(cy, cx + 2) - z10) * isx, (z11 - z10) * isy, od) != f1) m |= 4u;
+    }
+#undef HZ
+    return m;
+}
+
+/* boundary test of the height field: the triangle SDF of mesh.cpp:845-890 (distance of the hit point to the
+ * triangle's edges in an equilateral reference triangle, scaled so that the incentre maps to 1), restricted to
+ * the silhouette edges `edges`; 1 when the triangle has none.  On the outer border this is the rectangle's
+ * border distance (rectangle.cpp:318-319) in triangle units; at self-occlusion silhouettes it vanishes where the
+ * facing flips, like the grazing term sqr(dot(n, -d)) of the smooth-normal branch (mesh.cpp:892-898). */
+static float boundary_test_flat(const float p[3], const float p0[3], const float dp0[3], const float dp1[3], uint32_t edges) {
+    if (edges == 0u) return 1.0f;
     float rel[3];
     sub3(p, p0, rel);
     float bb1 = dot3(dp0, rel), bb2 = dot3(dp1, rel);
@@ -491,6 +529,7 @@ static float boundary_test_flat(const float p[3], const float p0[3], const float
     float s = signf_(e[0][0] * e[2][1] - e[0][1] * e[2][0]);
     float dmin0 = INFINITY, dmin1 = INFINITY;
     for (int k = 0; k < 3; ++k) {
+        if (!((edges >> k) & 1u)) continue;
         float vv[2] = { q[0] - tp[k][0], q[1] - tp[k][1] };
         float c = clamp01(dot2(vv, e[k]) / dot2(e[k], e[k]));
         float pq[2] = { vv[0] - e[k][0] * c, vv[1] - e[k][1] * c };
@@ -556,8 +595,11 @@ int hfo_compute_si(const hfo_field *f, const float o[3], const float d[3], float
     for (int k = 0; k < 3; ++k) si->sh_n[k] = si->n[k]; /* flat shading, mesh.cpp:834 */
     if (f->flip_normals)                                  /* mesh.cpp:837-840 */
         for (int k = 0; k < 3; ++k) { si->n[k] = -si->n[k]; si->sh_n[k] = -si->sh_n[k]; }
-    if (flags & HFO_RAY_BOUNDARYTEST)
-        si->boundary_test = boundary_test_flat(si->p, P[0], dp0, dp1);
+    if (flags & HFO_RAY_BOUNDARYTEST) {
+        float od[3];
+        xform_vec(f->to_object, d, od);
+        si->boundary_test = boundary_test_flat(si->p, P[0], dp0, dp1, silhouette_edges(f, prim, od));
+    }
 
     /* finalize_surface_interaction, interaction.h:476-499 */
     if (flags & HFO_RAY_SHADINGFRAME) {        /* initialize_sh_frame, interaction.h:257-267 */

@@ -11,10 +11,19 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 
 
 def test_adam_recovers_heights(hf):
+    """configs[4] as stated: the loss is the multi-light renders ONLY (no depth term), 100 Adam steps.
+    Shading under directional lights observes the surface gradient, so the recovered heights are compared after
+    removing the mean offset.  Measured: the image loss falls ~25x and the centred height error ~2.2x (0.117 ->
+    0.053) in 100 steps -- the slopes of the sine target reach 2.4, a third of the texels face away from some
+    lights (clamped cosines carry no gradient), which is what bounds a shading-only fit; the depth-supervised
+    variant of round 1 is still available as depth_weight > 0 and is checked separately."""
     import inverse_heights
-    hist, err, wall = inverse_heights.run(grid=64, film=128, spp=1, steps=60, lr=0.02, verbose=False)
-    assert hist[-1] < 0.1 * hist[0], (hist[0], hist[-1])      # the loss drops by > 10x
-    assert err < 0.12                                          # start: mean |0.5 - h*| ~ 0.17
+    hist, err, wall = inverse_heights.run(grid=64, film=128, spp=4, steps=100, lr=0.04, verbose=False)
+    assert hist[-1] < 0.1 * hist[0], (hist[0], hist[-1])      # the image loss drops by > 10x
+    start, end = inverse_heights.run.start_centred_error, inverse_heights.run.last_centred_error
+    assert end < start / 1.8, (start, end)
+    hist2, err2, _ = inverse_heights.run(grid=64, film=128, spp=1, steps=60, lr=0.02, verbose=False, depth_weight=10.0)
+    assert hist2[-1] < 0.1 * hist2[0] and err2 < 0.12
 
 
 def test_shadowed_lighting_matches_oracle_visibility(hf, oracle):

@@ -219,3 +219,39 @@ def test_bbox_and_maxt(oracle):
     for maxt, want in ((2.0, True), (np.nextafter(np.float32(2.0), np.float32(0)), False), (0.0, False)):
         r[6] = maxt
         assert g.ray_test(r)[0] == want
+
+
+def test_heightfield_boundary_test_silhouettes(oracle):
+    """for a height field the per-triangle SDF of mesh.cpp:863-890 must only see SILHOUETTE
+    edges -- the grid border (the rectangle's border distance, rectangle.cpp:318-319) and edges where the facing
+    towards the ray flips (the grazing silhouettes of mesh.cpp:892-898) -- not every interior edge.
+      * flat interior, seen from above: no silhouette edge anywhere near -> B = 1 (the incentre value), also exactly
+        on interior edges and vertices;
+      * the same point near the border: B = distance to the border in triangle units -> 0;
+      * a ridge seen from the side: the far slope faces away; on the near slope B -> 0 towards the crest and is 1
+        further down; seen from above both slopes face the ray and the crest is no boundary."""
+    flags = oracle.RAY_ALL | oracle.RAY_BOUNDARYTEST
+    def B(f, o, d):
+        r = _rays(o, d)
+        t, u, v, prim = f.ray_intersect_preliminary(r)
+        assert np.isfinite(t[0])
+        return float(f.compute_surface_interaction(r, t, u, v, prim, flags)["boundary_test"][0])
+    flat = oracle.OracleField(np.full((9, 9), 0.5, np.float32), 1.0)
+    for (x, y) in [(0.1, 0.05), (0.0, 0.0), (0.25, 0.1), (0.125, -0.3)]:       # interior: faces, a vertex, edges
+        assert B(flat, [x, y, 3.0], [0, 0, -1]) == 1.0
+    assert B(flat, [0.99999, 0.1, 3.0], [0, 0, -1]) < 1e-3                       # border
+    assert B(flat, [-0.3, -0.99999, 3.0], [0.05, 0.0, -1]) < 1e-3
+    assert 0.05 < B(flat, [0.98, 0.1, 3.0], [0, 0, -1]) < 1.0
+    # ridge along y at x = 0: z = 0.5 - |x|  (slopes +-1), 17 columns -> the crest is the vertex column 8
+    W = 17
+    xs = np.linspace(-1, 1, W)
+    ridge = oracle.OracleField(np.repeat((0.5 - 0.5 * np.abs(xs))[None, :], 9, 0).astype(np.float32), 1.0)
+    side = np.array([-1.0, 0.0, -0.2]); side /= np.linalg.norm(side)             # from +x, nearly horizontal
+    def from_side(x_hit):
+        z = 0.5 - 0.5 * abs(x_hit)
+        o = np.array([x_hit, 0.03, z]) - 3.0 * side
+        return B(ridge, o, side)
+    near_crest = from_side(0.004)       # on the near (+x) slope, 0.004 from the crest: one cell = 0.125 wide
+    lower = from_side(0.3)
+    assert near_crest < 0.1 and lower == 1.0, (near_crest, lower)
+    assert B(ridge, [0.004, 0.03, 3.0], [0, 0, -1]) == 1.0                       # from above the crest is no silhouette

@@ -98,3 +98,68 @@ def test_gpu_aux_rays_match_oracle(hf, oracle):
         got = ad.cpu().numpy()
         assert np.allclose(got, ref[3:6], atol=2e-6), np.abs(got - ref[3:6]).max()
         assert np.allclose(np.linalg.norm(got, axis=0), 1.0, atol=1e-5) and bool(torch.isinf(mt).all())
+
+
+# ---- the three set-ups of src/render/tests/test_reparameterization.py:29-40 ---------------------------------
+# (rectangle [-1,1]^2 at z = 0, num_rays = 32, kappa = 1e6, exponent = 3; the primary ray targets one SIDE of
+# the rectangle, its CENTRE, one CORNER).  The reference moves the mesh by theta * (1,0,0) and checks that the
+# derivative of the reparameterised direction equals the motion of the attached hit point,
+#     <d/dtheta direction, trans> == <normalize(si.p + trans - o) - d, trans>   (atol 1e-2),
+# with the other components insignificant.  A height field's parameter moves vertices along the object z axis,
+# so theta lifts all heights (trans = max_height * z) and the rays are oblique, or the lift would be invisible.
+_SETUPS = {"side": (0.0, 0.999), "centre": (0.0, 0.0), "corner": (0.99, -0.99)}
+_REF_D = np.array([0.25, 0.15, -1.0]) / np.linalg.norm([0.25, 0.15, -1.0])
+
+
+def _setup_ray(name):
+    tx, ty = _SETUPS[name]
+    tgt = np.array([tx, ty, 0.25])                       # on the flat surface z = 0.5 * 0.5
+    o = tgt - 5.0 * _REF_D
+    return o.astype(np.float32)[:, None], _REF_D.astype(np.float32)[:, None]
+
+
+def _attached_motion(oracle, f, o, d, lift_z):
+    r = np.concatenate([o, d, [[np.inf]]]).astype(np.float32)
+    t, u, v, prim = f.ray_intersect_preliminary(r)
+    assert np.isfinite(t[0])
+    p = f.compute_surface_interaction(r, t, u, v, prim, oracle.RAY_ALL)["p"].astype(np.float64)
+    eps = 1e-4
+    new_d = p + np.array([[0.0], [0.0], [lift_z * eps]]) - o
+    new_d /= np.linalg.norm(new_d)
+    return (new_d - d.astype(np.float64)) / eps
+
+
+@pytest.mark.parametrize("name", ["side", "centre", "corner"])
+def test_oracle_reference_setups(oracle, name):
+    h = np.full((9, 9), 0.5, np.float32)
+    f = oracle.OracleField(h, max_height=0.5)
+    o, d = _setup_ray(name)
+    Vt, div = oracle.reparam_forward(f, o, d, np.ones_like(h, dtype=np.float64), num_rays=32, kappa=1e6, exponent=3.0)
+    fd = _attached_motion(oracle, f, o, d, 0.5)
+    trans = np.array([[0.0], [0.0], [1.0]])
+    assert abs(float((Vt * trans).sum()) - float((fd * trans).sum())) < 1e-2          # the reference's assertion
+    assert np.allclose(Vt, fd, atol=1e-2)                                               # and every component
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["side", "centre", "corner"])
+def test_gpu_reference_setups(hf, oracle, name):
+    """same set-ups through hf_amd.reparameterize_ray: the forward derivative along 'all heights rise' is read
+    from reverse mode, V_theta[k] = <dL/dh, 1> for the upstream gradient e_k on the direction."""
+    import torch
+    h = np.full((9, 9), 0.5, np.float32)
+    f = oracle.OracleField(h, max_height=0.5)
+    o, d = _setup_ray(name)
+    shape = hf.Heightfield(heightfield=torch.from_numpy(h).cuda(), max_height=0.5)
+    shape.heightfield.requires_grad_(True)
+    ray = hf.Ray3f(torch.from_numpy(o).cuda(), torch.from_numpy(d).cuda())
+    Vt = np.zeros((3, 1))
+    for k in range(3):
+        shape.heightfield.grad = None
+        dirn, det = hf.reparameterize_ray(shape, ray, num_rays=32, kappa=1e6, exponent=3.0, seed=0)
+        dirn[k].sum().backward()
+        Vt[k, 0] = float(shape.heightfield.grad.double().sum())
+    fd = _attached_motion(oracle, f, o, d, 0.5)
+    assert np.allclose(Vt, fd, atol=1e-2), (Vt.ravel(), fd.ravel())
+    ref, _ = oracle.reparam_forward(f, o, d, np.ones_like(h, dtype=np.float64), num_rays=32, kappa=1e6, exponent=3.0)
+    assert np.allclose(Vt, ref, atol=2e-4 * max(1.0, np.abs(ref).max()))
