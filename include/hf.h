@@ -275,12 +275,18 @@ int hf_reparam_aux_rays(size_t n, const float *const o[3], const float *const d[
  * the outputs, grad_direction[3][n] and grad_divergence[n] (reparam.py:262-281: direction =
  * normalize(d + V / Z), divergence = (div - <V / Z, dZ>) / Z at V = 0), the gradient of this sample's
  * V_direct = (si.p - o) / si.t is written as upstream gradient of the auxiliary hit: grad_p[3][n] and
- * grad_t[n] (zero for misses), to be handed to hf_adjoint as hf_si_grad_t {p, t} with HF_RAY_FOLLOWSHAPE. */
+ * grad_t[n] (zero for misses), to be handed to hf_adjoint as hf_si_grad_t {p, t} with HF_RAY_FOLLOWSHAPE.
+ * grad_vd (optional, NULL = not wanted): the gradient with respect to this sample's V_direct itself,
+ * grad_vd[3][n] (zero for inactive lanes).  It is what the RAY needs (reparam.py:296-325 back-propagates to
+ * ray.o and ray.d as well): for a hit, dL/d(ray.o) = [grad_o of hf_adjoint] - grad_p; for a miss V_direct is
+ * ray.d itself and dL/d(ray.d) = grad_vd; dL/d(auxiliary direction) = [grad_d of hf_adjoint] is carried to
+ * ray.d through Frame3f(ray.d) by the host (mirror: hf_amd.reparameterize_ray). */
 int hf_reparam_weights(int mode, size_t n, const float *const o[3], const float *const d[3],
                        const uint8_t *active, uint32_t k, float kappa, float exponent, int antithetic,
                        uint32_t seed, const float *si_t, const float *const si_p[3], const float *si_boundary_test,
                        float *Z, float *const dZ[3], const float *const grad_direction[3],
-                       const float *grad_divergence, float *const grad_p[3], float *grad_t, hf_stream_t stream);
+                       const float *grad_divergence, float *const grad_p[3], float *grad_t,
+                       float *const grad_vd[3], hf_stream_t stream);
 
 /* ---- scalar / packet entry -----------------------------------------------------
  * Shape::ray_intersect_preliminary_scalar / _packet and ray_test_scalar / _packet

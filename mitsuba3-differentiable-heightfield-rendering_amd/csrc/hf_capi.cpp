@@ -513,7 +513,8 @@ extern "C" int hf_reparam_weights(int mode, size_t n, const float *const o[3], c
                                   uint32_t seed, const float *si_t, const float *const si_p[3],
                                   const float *si_boundary_test, float *Z, float *const dZ[3],
                                   const float *const grad_direction[3], const float *grad_divergence,
-                                  float *const grad_p[3], float *grad_t, hf_stream_t stream) {
+                                  float *const grad_p[3], float *grad_t, float *const grad_vd[3],
+                                  hf_stream_t stream) {
     if (!all3(o) || !all3(d) || !si_t || !si_boundary_test || !Z || !dZ || !dZ[0] || !dZ[1] || !dZ[2])
         return fail(HF_EINVAL, "hf_reparam_weights: NULL argument");
     if (mode != 0 && mode != 1) return fail(HF_EINVAL, "hf_reparam_weights: mode must be 0 or 1");
@@ -531,6 +532,7 @@ extern "C" int hf_reparam_weights(int mode, size_t n, const float *const o[3], c
         a.si_p[c] = si_p ? si_p[c] : nullptr;
         a.g_dir[c] = grad_direction ? grad_direction[c] : nullptr;
         a.g_p[c] = grad_p ? grad_p[c] : nullptr;
+        a.g_vd[c] = (grad_vd && grad_vd[0] && grad_vd[1] && grad_vd[2]) ? grad_vd[c] : nullptr;
     }
     hf_launch_reparam_weights(a, (hipStream_t) stream);
     HF_HIP(hipGetLastError());

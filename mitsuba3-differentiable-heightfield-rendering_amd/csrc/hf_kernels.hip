@@ -31,7 +31,9 @@
 
 #define HF_BLOCK 256
 #define HF_LDS_NODES 1366 // padding + pyramid depths 0..5 (1+4+16+64+256+1024 nodes) staged in LDS
+#ifndef HF_SUBTREE_LEVEL
 #define HF_SUBTREE_LEVEL 5 // the shared walk hands nodes of this level (32x32 cells) to the per-lane walk
+#endif
 
 // ---------------------------------------------------------------------------------
 // min/max mip pyramid (coarse-first, padded -- see hf_dev_field)
@@ -538,6 +540,15 @@ __device__ __forceinline__ void walk_packet(const hf_dev_field &f, const hf_lds_
     if ((threadIdx.x & 63u) < 8u) wcnt_base()[threadIdx.x & 63u] = 0u;
 #endif
     for (;;) {
+        // The state of the shared walk is wave-uniform by construction (it only ever depends on ballots), but the
+        // compiler's divergence analysis gives up on it across the per-lane walks inside this loop and would keep it
+        // -- and all the node addressing that derives from it -- in vector registers (flat loads, vector integer
+        // maths).  Reading it through the first lane pins it to scalar registers: scalar address arithmetic, LDS /
+        // scalar-cache loads with a uniform address, scalar branches.
+        X = (uint32_t) __builtin_amdgcn_readfirstlane((int) X); Y = (uint32_t) __builtin_amdgcn_readfirstlane((int) Y);
+        cur = (uint32_t) __builtin_amdgcn_readfirstlane((int) cur); L = __builtin_amdgcn_readfirstlane(L);
+        stk = ((uint64_t) (uint32_t) __builtin_amdgcn_readfirstlane((int) (stk >> 32)) << 32) |
+              (uint64_t) (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) stk);
         while (cur == 0u) { // node exhausted: pop
             if (L > top) goto done;
             cur = (uint32_t) stk & 15u; stk >>= 4;
@@ -590,14 +601,23 @@ __device__ __forceinline__ void walk_packet(const hf_dev_field &f, const hf_lds_
                 const uint32_t kd = (uint32_t) (top - (L - 1));
                 const uint32_t ix = X ^ (fxm >> L), iy = Y ^ (fym >> L);
                 const uint32_t base = hf_depth_off((int) kd) + ((2u * iy) << kd) + 2u * ix;
-                float2 b0, b1, b2, b3;
+                // the two x-adjacent children of a row are one aligned 16-byte entry pair (hf_depth_off); uniform
+                // address: LDS broadcast read for the staged depths, scalar-cache load beyond them
+                float4 c01, c23;
+#if HF_SHARED_LDS
                 if (base + (1u << kd) + 1u < HF_LDS_NODES) {
-                    b0 = s.node[base]; b1 = s.node[base + 1u]; b2 = s.node[base + (1u << kd)]; b3 = s.node[base + (1u << kd) + 1u];
-                } else {
-                    b0 = mip[base]; b1 = mip[base + 1u]; b2 = mip[base + (1u << kd)]; b3 = mip[base + (1u << kd) + 1u];
+                    c01 = *(const float4 *) &s.node[base];
+                    c23 = *(const float4 *) &s.node[base + (1u << kd)];
+                } else
+#endif
+                {
+                    // a scalar (uniform) global address: s_load through the scalar cache
+                    const uint32_t ub0 = (uint32_t) __builtin_amdgcn_readfirstlane((int) base);
+                    c01 = *(const float4 *) (mip + ub0);
+                    c23 = *(const float4 *) (mip + ub0 + (1u << kd));
                 }
-                q.lo[0] = b0.x; q.hi[0] = b0.y; q.lo[1] = b1.x; q.hi[1] = b1.y;
-                q.lo[2] = b2.x; q.hi[2] = b2.y; q.lo[3] = b3.x; q.hi[3] = b3.y;
+                q.lo[0] = c01.x; q.hi[0] = c01.y; q.lo[1] = c01.z; q.hi[1] = c01.w;
+                q.lo[2] = c23.x; q.hi[2] = c23.y; q.lo[3] = c23.z; q.hi[3] = c23.w;
             }
             const float S = (float) (1u << (L - 1));
             ml = child_mask(r, fx, fy, (float) X * (S + S), (float) Y * (S + S), S, q, r.gz, r.dz, r.mz, thi);
@@ -665,6 +685,12 @@ __device__ __forceinline__ void miss_si(hf_si_rec &si, v3 d, uint32_t flags) {
 #define HF_SCR_BYTES 1024
 #ifndef HF_DIST
 #define HF_DIST 2
+#endif
+#ifndef HF_EXP
+#define HF_EXP 0
+#endif
+#ifndef HF_SHARED_LDS
+#define HF_SHARED_LDS 0 // shared walk reads its boxes through the scalar cache (1: the staged depths from LDS)
 #endif
 #ifndef HF_TRACE_WAVES
 #define HF_TRACE_WAVES 5 // resident waves per SIMD = workgroups per CU of the traversal kernel (96 VGPRs)
@@ -828,7 +854,8 @@ __global__ __launch_bounds__(HF_BLOCK, HF_TRACE_WAVES) void hf_trace_kernel(hf_t
             if (am != 0ull) {
                 // coherent wave?  equal direction signs, entry points and directions close to the first live lane's
                 const int src = __builtin_ctzll(am);
-                const bool fx0 = __shfl((int) rs.fx, src) != 0, fy0 = __shfl((int) rs.fy, src) != 0;
+                // (v_readlane: the result is a scalar, so everything the shared walk derives from it stays scalar)
+                const bool fx0 = __builtin_amdgcn_readlane((int) rs.fx, src) != 0, fy0 = __builtin_amdgcn_readlane((int) rs.fy, src) != 0;
                 const float gx0 = __shfl(rs.gx, src), gy0 = __shfl(rs.gy, src);
                 const float ux = rs.r.idy, uy = rs.r.idx; // direction ratio proxy: compare idx/idy cross products
                 const float ux0 = __shfl(ux, src), uy0 = __shfl(uy, src);
@@ -873,6 +900,10 @@ __global__ __launch_bounds__(HF_BLOCK, HF_TRACE_WAVES) void hf_trace_kernel(hf_t
                 if (MODE == 2) {
                     hf_si_rec si;
                     const uint32_t flags = ka->flags;
+#if HF_EXP == 1   // experiment: no SI computation (records of hits are garbage)
+                    miss_si(si, dw, flags);
+                    si.t = best.hit ? best.t : si.t;
+#else
                     if (best.hit) {
                         // the origin is only needed by a hit: read again (an L2 hit) rather than held across the walk
                         const hf_rays_dev rp = load_rays(ka);
@@ -881,8 +912,21 @@ __global__ __launch_bounds__(HF_BLOCK, HF_TRACE_WAVES) void hf_trace_kernel(hf_t
                         compute_si(fl, ow, dw, best.t, best.u, best.v, best.prim, flags, si);
                     }
                     else          miss_si(si, dw, flags);
+#endif
+#if HF_EXP == 2   // experiment: SI computed, only one row stored
+                    {
+                        const hf_si_dev sio = load_si(ka);
+                        st(sio.t, ub, lo, si.t + si.p.x + si.n.y + si.dp_du.z + si.dp_dv.x + si.uv0 + si.sh_n.z);
+                    }
+#elif HF_EXP == 3 // experiment: records stored for the rays that hit only
+                    if (best.hit) {
+                        const hf_si_dev sio = load_si(ka);
+                        store_si(sio, ub, lo, si, flags);
+                    }
+#else
                     const hf_si_dev sio = load_si(ka); // all row pointers at once (wide scalar loads), then the stores
                     store_si(sio, ub, lo, si, flags);
+#endif
                 }
             }
         }
@@ -1382,9 +1426,9 @@ __global__ __launch_bounds__(HF_BLOCK) void hf_reparam_weight_kernel(hf_reparam_
         a.dZ[0][i] += dw.x; a.dZ[1][i] += dw.y; a.dZ[2][i] += dw.z;
         return;
     }
-    v3 gp = mk3(0.f, 0.f, 0.f);
+    v3 gp = mk3(0.f, 0.f, 0.f), gvd = mk3(0.f, 0.f, 0.f);
     float gt = 0.f;
-    if (hit) {
+    if (act) {
         // backward of direction = normalize(d + V/Z), divergence = (div - <V/Z, dZ>) / Z at V = 0 (reparam.py:262-281)
         const float Z = fmaxf(a.Z[i], 1e-8f), iZ = 1.0f / Z;
         const v3 gd = mk3(a.g_dir[0][i], a.g_dir[1][i], a.g_dir[2][i]);
@@ -1399,13 +1443,17 @@ __global__ __launch_bounds__(HF_BLOCK) void hf_reparam_weight_kernel(hf_reparam_
         // this sample: V_i = w V_direct, div_i = <d_w_omega, V_direct>, V_direct = (p - o) / t
         const v3 gVd = mk3(__builtin_fmaf(w, gV.x, gdivV * dw.x), __builtin_fmaf(w, gV.y, gdivV * dw.y),
                            __builtin_fmaf(w, gV.z, gdivV * dw.z));
-        const v3 po = mk3(a.si_p[0][i] - o.x, a.si_p[1][i] - o.y, a.si_p[2][i] - o.z);
-        const float it = 1.0f / t;
-        gp = mk3(gVd.x * it, gVd.y * it, gVd.z * it);
-        gt = -dot3(gVd, po) * it * it;
+        gvd = gVd;
+        if (hit) {
+            const v3 po = mk3(a.si_p[0][i] - o.x, a.si_p[1][i] - o.y, a.si_p[2][i] - o.z);
+            const float it = 1.0f / t;
+            gp = mk3(gVd.x * it, gVd.y * it, gVd.z * it);
+            gt = -dot3(gVd, po) * it * it;
+        }
     }
     a.g_p[0][i] = gp.x; a.g_p[1][i] = gp.y; a.g_p[2][i] = gp.z;
     a.g_t[i] = gt;
+    if (a.g_vd[0]) { a.g_vd[0][i] = gvd.x; a.g_vd[1][i] = gvd.y; a.g_vd[2][i] = gvd.z; }
 }
 
 void hf_launch_reparam_aux(const hf_reparam_args &a, hipStream_t stream) {

@@ -45,6 +45,7 @@ struct hf_reparam_args {
     float *Z, *dZ[3];                                 // mode 0: accumulated, mode 1: read
     const float *g_dir[3], *g_div;                    // mode 1
     float *g_p[3], *g_t;                              // mode 1 outputs
+    float *g_vd[3];                                   // mode 1, optional: gradient w.r.t. V_direct (ray gradients)
 };
 void hf_launch_reparam_aux(const hf_reparam_args &a, hipStream_t stream);
 void hf_launch_reparam_weights(const hf_reparam_args &a, hipStream_t stream);

@@ -663,25 +663,42 @@ def _p3(x):
     return (C.c_void_p * 3)(x[0].data_ptr(), x[1].data_ptr(), x[2].data_ptr())
 
 
+def _coordinate_system(n):
+    """coordinate_system(), include/mitsuba/core/vector.h:116-136, on [3, k] tensors (differentiable)"""
+    sign = torch.where(n[2] >= 0, torch.ones_like(n[2]), -torch.ones_like(n[2]))
+    a = -1.0 / (sign + n[2])
+    b = n[0] * n[1] * a
+    s = torch.stack([torch.where(n[2] >= 0, n[0] * n[0] * a, -(n[0] * n[0] * a)) + 1.0,
+                     torch.where(n[2] >= 0, b, -b),
+                     torch.where(n[2] >= 0, -n[0], n[0])])
+    t = torch.stack([b, n[1] * (n[1] * a) + sign, -n[1]])
+    return s, t
+
+
 class _ReparameterizeOp(torch.autograd.Function):
-    """reparam.py:126-333 for a scene that is one heightfield: identity in primal mode, the warped-area
-    gradient of (direction, determinant) with respect to the heights in backward mode."""
+    """reparam.py:126-333 for a scene that is one heightfield: identity in primal mode; in backward mode the
+    warped-area gradient of (direction, determinant) with respect to the heights AND the ray (reparam.py:296-325
+    accumulates grad(ray.o), grad(ray.d) over the auxiliary samples)."""
 
     @staticmethod
-    def forward(ctx, heightfield, shape, ray, num_rays, kappa, exponent, antithetic, seed, active):
-        ctx.shape, ctx.ray = shape, ray
+    def forward(ctx, heightfield, ray_o, ray_d, shape, num_rays, kappa, exponent, antithetic, seed, active):
+        ctx.shape = shape
+        ctx.save_for_backward(ray_o, ray_d)
         ctx.cfg = (int(num_rays), float(kappa), float(exponent), bool(antithetic), int(seed), active)
-        n = ray.o.shape[1]
-        return ray.d.detach().clone(), torch.ones(n, dtype=torch.float32, device=ray.o.device)
+        n = ray_o.shape[1]
+        return ray_d.detach().clone(), torch.ones(n, dtype=torch.float32, device=ray_o.device)
 
     @staticmethod
     def backward(ctx, grad_direction, grad_divergence):
-        shape, ray = ctx.shape, ctx.ray
+        shape = ctx.shape
+        ray_o, ray_d = ctx.saved_tensors
         num_rays, kappa, exponent, antithetic, seed, active = ctx.cfg
+        need_h, need_o, need_d = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        ray_grads = need_o or need_d
         L = _capi.lib()
-        dev = ray.o.device
-        n = ray.o.shape[1]
-        o = ray.o.detach().to(torch.float32).contiguous(); d = ray.d.detach().to(torch.float32).contiguous()
+        dev = ray_o.device
+        n = ray_o.shape[1]
+        o = ray_o.detach().to(torch.float32).contiguous(); d = ray_d.detach().to(torch.float32).contiguous()
         gd = grad_direction.to(torch.float32).contiguous(); gdiv = grad_divergence.to(torch.float32).contiguous()
         act = None if active is None else active.to(torch.uint8).contiguous()
         act_p = None if act is None else act.data_ptr()
@@ -697,6 +714,11 @@ class _ReparameterizeOp(torch.autograd.Function):
         g_s.t = g_t.data_ptr()
         for c in range(3):
             g_s.p[c] = g_p[c].data_ptr()
+        if ray_grads:   # per-sample ray gradients of the auxiliary hit + the gradient w.r.t. V_direct itself
+            g_vd = torch.empty((3, n), dtype=torch.float32, device=dev); gvd_p = _p3(g_vd)
+            go_adj = torch.empty((3, n), dtype=torch.float32, device=dev); gd_adj = torch.empty((3, n), dtype=torch.float32, device=dev)
+            go_adj_p, gd_adj_p = _p3(go_adj), _p3(gd_adj)
+            grad_o = torch.zeros((3, n), dtype=torch.float32, device=dev); grad_d = torch.zeros((3, n), dtype=torch.float32, device=dev)
         # The auxiliary hits of the first loop (36 B per ray and sample: pi + si.t, si.p, si.boundary_test) are kept
         # for the second one when they fit; the reference re-traces (reparam.py:296-325), which is the fallback.
         keep = 36 * n * num_rays <= (16 << 30)
@@ -727,7 +749,8 @@ class _ReparameterizeOp(torch.autograd.Function):
             sp_p = (C.c_void_p * 3)(*rows[1:4])
             check(L.hf_reparam_weights(mode, n, C.byref(o_p), C.byref(d_p), act_p, k, kappa, exponent, int(antithetic),
                                        seed, rows[0], C.byref(sp_p), rows[4], Z.data_ptr(), C.byref(dZ_p), C.byref(gd_p),
-                                       gdiv.data_ptr(), C.byref(gp_p), g_t.data_ptr(), stream))
+                                       gdiv.data_ptr(), C.byref(gp_p), g_t.data_ptr(),
+                                       C.byref(gvd_p) if (ray_grads and mode == 1) else None, stream))
 
         for k in range(num_rays):           # weight normalisation (reparam.py:236-256)
             buf = bufs[k if keep else 0]
@@ -740,19 +763,39 @@ class _ReparameterizeOp(torch.autograd.Function):
                 trace(k, buf)
             weights(1, k, buf)
             rows, si_s, pi_s = structs(buf)
-            check(L.hf_adjoint(shape._h, n, C.byref(r_s), C.byref(pi_s), flags, None, C.byref(g_s),
-                               grad_h.data_ptr(), None, None, stream))
+            check(L.hf_adjoint(shape._h, n, C.byref(r_s), C.byref(pi_s), flags, act_p, C.byref(g_s),
+                               grad_h.data_ptr() if need_h else None,
+                               C.byref(go_adj_p) if ray_grads else None, C.byref(gd_adj_p) if ray_grads else None, stream))
+            if ray_grads:
+                hit = torch.isfinite(buf[0])
+                if act is not None:
+                    hit = hit & (act != 0)
+                # hit: V_direct = (p - o) / t  ->  dL/do = [t's dependence on o: hf_adjoint] - gVd / t  (= g_p);
+                #      t's dependence on the auxiliary direction d_aux = Frame3f(d).to_world(omega) goes on to d
+                # miss: V_direct = ray.d (reparam.py:93-95)  ->  dL/dd = gVd
+                grad_o += torch.where(hit, go_adj - g_p, torch.zeros_like(g_p))
+                if need_d:
+                    with torch.enable_grad():
+                        dq = d.detach().clone().requires_grad_(True)
+                        s_, t_ = _coordinate_system(dq)
+                        sd, td = s_.detach(), t_.detach()
+                        om = torch.stack([(sd * aux_d).sum(0), (td * aux_d).sum(0), (d * aux_d).sum(0)])  # omega_local
+                        d_aux = s_ * om[0] + t_ * om[1] + dq * om[2]
+                        (gd_through,) = torch.autograd.grad(d_aux, dq, torch.where(hit, gd_adj, torch.zeros_like(gd_adj)))
+                    grad_d += gd_through + torch.where(hit, torch.zeros_like(g_vd), g_vd)
         gh = grad_h
-        hf = ctx.needs_input_grad[0]
         if gh.shape != shape.heightfield.shape:
             gh = gh.reshape(shape.heightfield.shape)
-        return (gh if hf else None), None, None, None, None, None, None, None, None
+        return ((gh if need_h else None), (grad_o if need_o else None), (grad_d if need_d else None),
+                None, None, None, None, None, None, None)
 
 
 def reparameterize_ray(shape, ray, num_rays=4, kappa=1e5, exponent=3.0, antithetic=False, seed=0, active=None):
     """``mitsuba.ad.reparameterize_ray`` (reparam.py:336-420) for a scene made of this heightfield: returns
-    ``(direction, det)`` = ``(ray.d, 1)`` whose gradients flow into ``shape.heightfield`` through ``num_rays``
-    auxiliary rays per ray (von Mises-Fisher around ``ray.d``, harmonic weights from ``si.boundary_test``,
-    hits followed with ``RayFlags.FollowShape``).  ``ray.d`` must be unit length.  Gradients with respect to
-    the ray itself are not propagated; PCG32 is replaced by sample_tea_32(seed, ...) (include/hf.h)."""
-    return _ReparameterizeOp.apply(shape.heightfield, shape, ray, num_rays, kappa, exponent, antithetic, seed, active)
+    ``(direction, det)`` = ``(ray.d, 1)`` -- the reparameterisation is the identity in primal mode, exactly as in
+    the reference (reparam.py:139-155) -- whose gradients flow into ``shape.heightfield`` and into ``ray.o`` /
+    ``ray.d`` (when those require grad) through ``num_rays`` auxiliary rays per ray (von Mises-Fisher around
+    ``ray.d``, harmonic weights from ``si.boundary_test``, hits followed with ``RayFlags.FollowShape``).
+    ``ray.d`` must be unit length.  PCG32 is replaced by sample_tea_32(seed, ...) (include/hf.h)."""
+    return _ReparameterizeOp.apply(shape.heightfield, ray.o, ray.d, shape, num_rays, kappa, exponent, antithetic, seed,
+                                   active)

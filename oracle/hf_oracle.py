@@ -368,9 +368,13 @@ def _reparam_weight(d, k, kappa, exponent, antithetic, seed, t, bt):
 
 
 def reparam_backward(field, o, d, grad_direction, grad_divergence, num_rays=4, kappa=1e5, exponent=3.0,
-                     antithetic=False, seed=0, active=None, nthreads=0):
-    """dL/dheight through reparameterize_ray (reparam.py:224-333, backward_symbolic, shape parameter only):
-    given the upstream gradients of its outputs (direction [3,n], divergence [n])."""
+                     antithetic=False, seed=0, active=None, nthreads=0, ray_grads=False):
+    """dL/dheight through reparameterize_ray (reparam.py:224-333, backward_symbolic): given the upstream gradients
+    of its outputs (direction [3,n], divergence [n]).  With ray_grads also (dL/d ray.o, dL/d ray.d) [3,n] each
+    (reparam.py:296-325): per sample L_i = <gVd_i, V_direct_i(o, d)> with everything else detached, where
+    V_direct = (p - o) / t, t = |p - o| / |d_aux|, d_aux = Frame3f(d).to_world(omega) for a hit (p is glued to the
+    shape: FollowShape) and V_direct = d for a miss; differentiated here by float64 central differences of exactly
+    that expression -- independent of the analytic chain the kernels and the host mirror use."""
     o = np.asarray(o, np.float32); d = np.asarray(d, np.float32)
     n = o.shape[1]
     act = np.ones(n, bool) if active is None else (np.asarray(active) != 0)
@@ -389,14 +393,31 @@ def reparam_backward(field, o, d, grad_direction, grad_divergence, num_rays=4, k
     gV = (gd - dd * ((dd * gd).sum(0) / n2)) / np.sqrt(n2) / Z - gdiv / (Z * Z) * dZ
     gdivV = gdiv / Z
     gh = np.zeros((field.H, field.W), np.float64)
-    for (r, t, u, v, prim, si, hit, w, dw) in recs:               # third loop: back-propagate every sample
+    go_ray = np.zeros((3, n)); gd_ray = np.zeros((3, n))
+    for k, (r, t, u, v, prim, si, hit, w, dw) in enumerate(recs):  # third loop: back-propagate every sample
         gVd = w * gV + gdivV * dw
+        if ray_grads:
+            om = reparam_aux_sample(d, k, kappa, antithetic, seed)[0]
+            p64 = si["p"].astype(np.float64)
+            def L(o_, d_):
+                fs, ft = _coordinate_system_np(d_)
+                da = fs * om[0] + ft * om[1] + d_ * om[2]
+                po = p64 - o_
+                tt = np.sqrt((po * po).sum(0) / (da * da).sum(0))
+                Vd = np.where(hit, po / np.where(hit, tt, 1.0), d_)
+                return (gVd * Vd).sum(0) * act                     # per ray: rays are independent
+            o64 = o.astype(np.float64)
+            eps = 1e-6
+            for c in range(3):
+                e = np.zeros((3, 1)); e[c] = eps
+                go_ray[c] += (L(o64 + e, dd) - L(o64 - e, dd)) / (2 * eps)
+                gd_ray[c] += (L(o64, dd + e) - L(o64, dd - e)) / (2 * eps)
         tt = np.where(hit, si["t"].astype(np.float64), 1.0)
         po = si["p"].astype(np.float64) - o.astype(np.float64)
         gp = np.where(hit, gVd / tt, 0.0)
         gt = np.where(hit, -(gVd * po).sum(0) / (tt * tt), 0.0)
         gh += field.adjoint(r, t, u, v, prim, {"p": gp.astype(np.float32), "t": gt.astype(np.float32)[None]}, flags, nthreads=nthreads)
-    return gh
+    return (gh, go_ray, gd_ray) if ray_grads else gh
 
 
 def reparam_forward(field, o, d, dheights, num_rays=4, kappa=1e5, exponent=3.0, antithetic=False, seed=0, active=None):

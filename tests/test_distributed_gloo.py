@@ -1,7 +1,8 @@
-"""N > 1 path on CPU: world_size-2 gloo.  Rays shard over ranks (each rank its own spp seed,
-bench.py's partition), every rank accumulates a private dL/dheight texture, one all-reduce sums
-them (hf_amd.allreduce_gradient).  The per-rank compute is done with the CPU oracle here; the
-check is that the sharded + all-reduced gradient equals the single-process one."""
+"""N > 1 path on CPU: world_size-2 gloo.  ONE wavefront is cut into image tiles (hf_amd.workload.partition_tiles,
+bench.py's strong-scaling partition, BASELINE configs[3]); every rank traces its tiles, accumulates a private
+dL/dheight texture, one all-reduce sums them (hf_amd.allreduce_gradient).  No GPU here, so the per-rank compute is
+the CPU oracle; the check is that tiles + all-reduce reproduce the single-process gradient of the whole wavefront.
+The same partition through the HIP kernels is checked on one device by tests/test_partition.py (virtual ranks)."""
 import os
 import sys
 
@@ -13,11 +14,16 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _grad_for_seed(seed):
+FILM, SPP, TILE = 48, 2, 8
+
+
+def _grad_for_rank(rank, world):
+    """gradient texture of rank `rank` of `world` (world = 1: the whole wavefront)"""
     import hf_amd
     from oracle import hf_oracle as O
     h = hf_amd.workload.sine_heights(32, 32).numpy()
-    r = hf_amd.workload.ortho_rays(24, 24, 2, "cpu", seed=seed).numpy()
+    pixels = hf_amd.workload.partition_tiles(FILM, FILM, world, tile=TILE)[rank]
+    r = hf_amd.workload.ortho_rays(FILM, FILM, SPP, "cpu", pixels=pixels).numpy()
     f = O.OracleField(h, max_height=0.5)
     t, u, v, prim = f.ray_intersect_preliminary(r, nthreads=1)
     si = f.compute_surface_interaction(r, t, u, v, prim, nthreads=1)
@@ -32,7 +38,7 @@ def _worker(rank, world, port, out):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import hf_amd
-    g = torch.from_numpy(_grad_for_seed(rank).copy())
+    g = torch.from_numpy(_grad_for_rank(rank, world).copy())
     hf_amd.allreduce_gradient(g)
     if rank == 0:
         np.save(out, g.numpy())
@@ -45,10 +51,11 @@ def test_sharded_gradient_allreduce(tmp_path):
     world, port = 2, 29500 + (os.getpid() % 1000)
     out = str(tmp_path / "g.npy")
     mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
-    want = _grad_for_seed(0).astype(np.float64) + _grad_for_seed(1).astype(np.float64)
+    want = _grad_for_rank(0, 1).astype(np.float64)          # the un-partitioned wavefront
     got = np.load(out)
     assert np.abs(want).max() > 0
     assert np.allclose(got, want, rtol=1e-5, atol=1e-6)
+    assert np.abs(_grad_for_rank(0, 2)).max() > 0 and np.abs(_grad_for_rank(1, 2)).max() > 0   # both ranks contribute
 
 
 def test_allreduce_is_identity_without_process_group():

@@ -163,3 +163,35 @@ def test_gpu_reference_setups(hf, oracle, name):
     assert np.allclose(Vt, fd, atol=1e-2), (Vt.ravel(), fd.ravel())
     ref, _ = oracle.reparam_forward(f, o, d, np.ones_like(h, dtype=np.float64), num_rays=32, kappa=1e6, exponent=3.0)
     assert np.allclose(Vt, ref, atol=2e-4 * max(1.0, np.abs(ref).max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kappa,antithetic,num_rays", [(30.0, False, 5), (2000.0, True, 8)])
+def test_gpu_reparameterize_ray_gradients_of_the_ray(hf, oracle, kappa, antithetic, num_rays):
+    """reparam.py:296-325 also back-propagates to ray.o and ray.d.  The host mirror's analytic chain (hf_adjoint's
+    grad_o / grad_d of the FollowShape hit, minus grad_p, through Frame3f(d)) against the oracle's float64 central
+    differences of <gVd, V_direct(o, d)>; rays near the border so that some auxiliary rays miss (V_direct = d)."""
+    import torch
+    h, f = _scene(oracle, seed=5)
+    rng = np.random.default_rng(6)
+    n = 1500
+    o, d = _rays(n, rng)
+    o[0:2] *= 1.25                                   # spread the targets beyond the border
+    shape = hf.Heightfield(heightfield=torch.from_numpy(h).cuda(), max_height=0.5)
+    shape.heightfield.requires_grad_(True)
+    ot = torch.from_numpy(o).cuda().requires_grad_(True); dt = torch.from_numpy(d).cuda().requires_grad_(True)
+    dirn, det = hf.reparameterize_ray(shape, hf.Ray3f(ot, dt), num_rays=num_rays, kappa=kappa, exponent=3.0,
+                                      antithetic=antithetic, seed=7)
+    gd = rng.normal(size=(3, n)).astype(np.float32); gdiv = rng.normal(size=n).astype(np.float32)
+    ((dirn * torch.from_numpy(gd).cuda()).sum() + (det * torch.from_numpy(gdiv).cuda()).sum()).backward()
+    gh_ref, go_ref, gdr_ref = oracle.reparam_backward(f, o, d, gd, gdiv, num_rays=num_rays, kappa=kappa, exponent=3.0,
+                                                      antithetic=antithetic, seed=7, ray_grads=True)
+    got_h = shape.heightfield.grad.cpu().numpy().astype(np.float64)
+    assert np.linalg.norm(got_h - gh_ref) <= 3e-5 * np.linalg.norm(gh_ref)
+    go, gdr = ot.grad.cpu().numpy().astype(np.float64), dt.grad.cpu().numpy().astype(np.float64)
+    assert np.linalg.norm(go_ref) > 0 and np.linalg.norm(gdr_ref) > 0
+    # some auxiliary rays must have missed for the V_direct = d branch to be exercised
+    r = oracle.reparam_aux_rays(o, d, 0, kappa, antithetic, 7)
+    assert 0.02 < np.isinf(f.ray_intersect_preliminary(r)[0]).mean() < 0.9
+    assert np.linalg.norm(go - go_ref) <= 2e-4 * np.linalg.norm(go_ref), np.linalg.norm(go - go_ref) / np.linalg.norm(go_ref)
+    assert np.linalg.norm(gdr - gdr_ref) <= 2e-4 * np.linalg.norm(gdr_ref), np.linalg.norm(gdr - gdr_ref) / np.linalg.norm(gdr_ref)
