@@ -89,7 +89,7 @@ __host__ __device__ __forceinline__ int hf_level_w(int cells, int l) { return (c
 __host__ __device__ __forceinline__ uint32_t hf_depth_off(int k) { return (0x55555555u & ((1u << (2 * k)) - 1u)) + 1u; }
 
 // Sheared bounds.  Min/max boxes are loose on steep terrain: a node on a slope spans a large
-// z range although the surface stays close to a plane.  Nodes of levels 2..HF_SHEAR_TOP therefore
+// z range although the surface stays close to a plane.  Nodes of levels 1..HF_SHEAR_TOP therefore
 // also carry a plane  z = c + a (x - xc) + b (y - yc)  through their corner heights (x, y in cell
 // units, (xc,yc) the node centre) and, per child, the exact range of  z - plane  over the child's
 // vertices: the box test of the walk then runs in the sheared coordinate  w = z - plane, in which
@@ -98,8 +98,8 @@ __host__ __device__ __forceinline__ uint32_t hf_depth_off(int k) { return (0x555
 // actual order j = 2 jy + jx, absent children (+inf, -inf).  Same coarse-first indexing as the
 // pyramid: node (ix,iy) of level L = depth k = top - L is record  hf_depth_off(k) - 1 + (iy << k) + ix.
 #define HF_SHEAR_TOP 5
-__host__ __device__ __forceinline__ size_t hf_shear_records(int top) { // depths 0 .. top-2 (levels 2 .. top)
-    return top >= 2 ? (size_t) hf_depth_off(top - 1) - 1u : 0u;
+__host__ __device__ __forceinline__ size_t hf_shear_records(int top) { // depths 0 .. top-1 (levels 1 .. top)
+    return (size_t) hf_depth_off(top) - 1u;
 }
 
 struct hf_hit {

@@ -30,7 +30,6 @@
 #include "hf_launch.h"
 
 #define HF_BLOCK 256
-#define HF_LDS_NODES 1366 // padding + pyramid depths 0..5 (1+4+16+64+256+1024 nodes) staged in LDS
 #ifndef HF_SUBTREE_LEVEL
 #define HF_SUBTREE_LEVEL 5 // the shared walk hands nodes of this level (32x32 cells) to the per-lane walk
 #endif
@@ -136,7 +135,7 @@ __global__ __launch_bounds__(HF_BLOCK) void hf_shear_minmax_kernel(const float2 
 
 void hf_launch_build_mips(const hf_dev_field &f, float2 *mip, float4 *shear, hipStream_t stream) {
     const int top = f.top;
-    for (int L = 2; L <= top && L <= HF_SHEAR_TOP; ++L) {
+    for (int L = 1; L <= top && L <= HF_SHEAR_TOP; ++L) { // level 1: the children are the cells themselves
         const int k = top - L, n = 1 << (2 * k);
         float4 *recs = shear + (size_t) (hf_depth_off(k) - 1u) * 3;
         hipLaunchKernelGGL(hf_shear_kernel, dim3((4 * n + HF_BLOCK - 1) / HF_BLOCK), dim3(HF_BLOCK), 0, stream, f.h, f.W,
@@ -163,17 +162,6 @@ void hf_launch_build_mips(const hf_dev_field &f, float2 *mip, float4 *shear, hip
 // ---------------------------------------------------------------------------------
 // traversal
 // ---------------------------------------------------------------------------------
-struct hf_lds_mips {
-    float2 node[HF_LDS_NODES]; // the first (coarsest) nodes of the pyramid
-};
-
-__device__ __forceinline__ void stage_mips(const hf_dev_field &f, hf_lds_mips &s) {
-    const uint32_t total = hf_depth_off(f.top);
-    const uint32_t cnt = total < HF_LDS_NODES ? total : HF_LDS_NODES;
-    for (uint32_t k = threadIdx.x; k < cnt; k += HF_BLOCK) s.node[k] = f.mip[k];
-    __syncthreads();
-}
-
 #ifdef HF_WSTATS
 // wave-level execution counters: WCOUNT(k) adds 1 per wave each time the enclosing code runs with any lane
 __device__ __forceinline__ uint32_t *wcnt_base() {
@@ -325,48 +313,6 @@ __device__ __forceinline__ void shear_line(const hf_dev_field &f, const hf_ray_s
     mz = __builtin_fmaf(sab, m, r.mz);
 }
 
-// 3x3 heights -> the 2x2 cells of a block as exact (sheared) boxes -> mask (ACTUAL numbering j = 2*jy+jx)
-// of the cells the fat ray can hit.  (c0,r0) = actual lower-left cell of the block, (fX,fY) = its
-// order-space origin.  The triangles themselves are tested later, wave-converged (walk_subtree).
-template <typename LoadH>
-__device__ __forceinline__ uint32_t block_cells(const hf_dev_field &f, const hf_ray_state &rs, bool fx, bool fy, int c0,
-                                                int r0, float fX, float fY, float thi, LoadH loadh) {
-    const hf_trav &r = rs.r;
-    const int cw = f.W - 1, ch = f.H - 1;
-    const int ca = min(max(c0, 0), f.W - 1), cb = min(max(c0 + 1, 0), f.W - 1), cc = min(max(c0 + 2, 0), f.W - 1);
-    const int ra = min(max(r0, 0), f.H - 1), rb = min(max(r0 + 1, 0), f.H - 1), rc = min(max(r0 + 2, 0), f.H - 1);
-    const float z00 = loadh(ra, ca) * f.s, z01 = loadh(ra, cb) * f.s, z02 = loadh(ra, cc) * f.s;
-    const float z10 = loadh(rb, ca) * f.s, z11 = loadh(rb, cb) * f.s, z12 = loadh(rb, cc) * f.s;
-    const float z20 = loadh(rc, ca) * f.s, z21 = loadh(rc, cb) * f.s, z22 = loadh(rc, cc) * f.s;
-    const bool vx0 = (c0 >= 0) & (c0 < cw), vx1 = (c0 + 1 >= 0) & (c0 + 1 < cw);
-    const bool vy0 = (r0 >= 0) & (r0 < ch), vy1 = (r0 + 1 >= 0) & (r0 + 1 < ch);
-    // sheared by the plane through the block's corner heights (hf_device.h): w = z - plane at the 9 vertices
-    const float a = 0.25f * ((z02 - z00) + (z22 - z20)), b = 0.25f * ((z20 - z00) + (z22 - z02));
-    const float c = 0.25f * ((z00 + z02) + (z20 + z22));
-    const float p0 = c - b, p2 = c + b;
-    const float w00 = z00 - (p0 - a), w01 = z01 - p0, w02 = z02 - (p0 + a);
-    const float w10 = z10 - (c - a), w11 = z11 - c, w12 = z12 - (c + a);
-    const float w20 = z20 - (p2 - a), w21 = z21 - p2, w22 = z22 - (p2 + a);
-    const float inf = __builtin_inff();
-    hf_quad q;
-    q.lo[0] = (vx0 & vy0) ? fminf(fminf(w00, w01), fminf(w10, w11)) : inf;
-    q.hi[0] = (vx0 & vy0) ? fmaxf(fmaxf(w00, w01), fmaxf(w10, w11)) : -inf;
-    q.lo[1] = (vx1 & vy0) ? fminf(fminf(w01, w02), fminf(w11, w12)) : inf;
-    q.hi[1] = (vx1 & vy0) ? fmaxf(fmaxf(w01, w02), fmaxf(w11, w12)) : -inf;
-    q.lo[2] = (vx0 & vy1) ? fminf(fminf(w10, w11), fminf(w20, w21)) : inf;
-    q.hi[2] = (vx0 & vy1) ? fmaxf(fmaxf(w10, w11), fmaxf(w20, w21)) : -inf;
-    q.lo[3] = (vx1 & vy1) ? fminf(fminf(w11, w12), fminf(w21, w22)) : inf;
-    q.hi[3] = (vx1 & vy1) ? fmaxf(fmaxf(w11, w12), fmaxf(w21, w22)) : -inf;
-    float gz, dz, mz;
-    shear_line(f, rs, fx, fy, a, b, c, __builtin_fabsf(a) + __builtin_fabsf(b), fX + 1.f, fY + 1.f, gz, dz, mz);
-    mz += 1e-6f * (__builtin_fabsf(c) + __builtin_fabsf(a) + __builtin_fabsf(b)); // rounding of the w's
-    {   // needle triangles (see walk_subtree): m cells beside the ray are up to m x (range of the cell) above / below it
-        const float rmax = fmaxf(fmaxf(q.hi[0] - q.lo[0], q.hi[1] - q.lo[1]), fmaxf(q.hi[2] - q.lo[2], q.hi[3] - q.lo[3]));
-        mz = __builtin_fmaf(0.5f * (r.gxm - r.gxp), rmax, mz);
-    }
-    return child_mask(r, fx, fy, fX, fY, 1.f, q, gz, dz, mz, thi);
-}
-
 // actual-child mask -> order-space child mask (bit k = bit (k ^ flip))
 __device__ __forceinline__ uint32_t to_order(uint32_t m, bool fx, bool fy) {
     if (fx) m = ((m & 5u) << 1) | ((m >> 1) & 5u);
@@ -401,18 +347,16 @@ struct hf_src_global {
 struct hf_walk {
     uint32_t X, Y, cur, pend; // node (X,Y) of level L, its order-space children still to visit; candidate cells
     uint64_t stk;             // 4 bits per level: the ancestors' pending children (L0 can be the root of a 2^15-cell grid)
-    int L, pc0, pr0;          // level; actual lower-left cell of the parked block
-    float pfx, pfy;           // order-space origin of the parked block
-    bool fin, pblk;           // subtree exhausted / parked on a level-1 node
+    int L, pc0, pr0;          // level; actual lower-left cell of the 2x2 block the candidate cells belong to
+    bool fin;                 // subtree exhausted
 };
 // start one level above the subtree root: a virtual parent whose only pending child is the root
 __device__ __forceinline__ void walk_init(hf_walk &w, uint32_t X0, uint32_t Y0, int L0) {
     w.X = X0 >> 1; w.Y = Y0 >> 1; w.cur = 1u << ((X0 & 1u) | ((Y0 & 1u) << 1)); w.pend = 0u;
-    w.stk = 0ull; w.L = L0 + 1; w.pc0 = 0; w.pr0 = 0; w.pfx = 0.f; w.pfy = 0.f; w.fin = false; w.pblk = false;
+    w.stk = 0ull; w.L = L0 + 1; w.pc0 = 0; w.pr0 = 0; w.fin = false;
 }
 __device__ __forceinline__ void walk_idle(hf_walk &w) {
-    w.X = 0u; w.Y = 0u; w.cur = 0u; w.pend = 0u; w.stk = 0ull; w.L = 0; w.pc0 = 0; w.pr0 = 0; w.pfx = 0.f; w.pfy = 0.f;
-    w.fin = true; w.pblk = false;
+    w.X = 0u; w.Y = 0u; w.cur = 0u; w.pend = 0u; w.stk = 0ull; w.L = 0; w.pc0 = 0; w.pr0 = 0; w.fin = true;
 }
 
 // One round of the walk for every lane of the call: walk until parked or done, then the parked blocks, then
@@ -424,7 +368,7 @@ __device__ __forceinline__ bool walk_round(const hf_dev_field &f, const Src &src
     auto loadh = [&src](int i, int j) { return src.height(i, j); };
     bool hit_any = false;
     // ---- walk until this lane reaches a level-1 node (parks on it) or has exhausted the subtree ----
-    while (!w.fin && !w.pblk) {
+    while (!w.fin && w.pend == 0u) {
         WCOUNT(3);
         if (w.cur == 0u) {
             // Node exhausted: pop.  Every level between here and the nearest ancestor with pending children is
@@ -443,12 +387,6 @@ __device__ __forceinline__ bool walk_round(const hf_dev_field &f, const Src &src
         // the mask may predate a hit: re-check the child's entry against the current t_hi
         const float te = fmaxf(((float) cx * S - r.gxm) * r.idx, ((float) cy * S - r.gym) * r.idy);
         if (te > thi) continue;
-        if (w.L == 2) { // child is a level-1 node: park, its 2x2 cells are examined wave-converged below
-            w.pc0 = (int) (2u * (cx ^ (fxm >> 1))); w.pr0 = (int) (2u * (cy ^ (fym >> 1)));
-            w.pfx = (float) (2u * cx); w.pfy = (float) (2u * cy);
-            w.pblk = true;
-            continue;
-        }
         WCOUNT(5);
         w.stk = (w.stk << 4) | (uint64_t) w.cur;
         w.X = cx; w.Y = cy; --w.L;
@@ -467,15 +405,19 @@ __device__ __forceinline__ bool walk_round(const hf_dev_field &f, const Src &src
             q.lo[0] = q01.x; q.hi[0] = q01.y; q.lo[1] = q01.z; q.hi[1] = q01.w;
             q.lo[2] = q23.x; q.hi[2] = q23.y; q.lo[3] = q23.z; q.hi[3] = q23.w;
         }
-        w.cur = to_order(child_mask(r, fx, fy, (float) w.X * S, (float) w.Y * S, Sc, q, gz, dz, mz, thi), fx, fy);
+        const uint32_t m = child_mask(r, fx, fy, (float) w.X * S, (float) w.Y * S, Sc, q, gz, dz, mz, thi);
+        if (w.L == 1) {
+            // the children of a level-1 node are cells: they become this lane's candidates (ACTUAL numbering
+            // j = 2 jy + jx, tested in any order -- the result is order independent) and the lane stops walking
+            // until the converged triangle rounds below have run
+            w.pend = m;
+            w.pc0 = (int) (2u * ix); w.pr0 = (int) (2u * iy);
+            w.cur = 0u;
+        } else {
+            w.cur = to_order(m, fx, fy);
+        }
     }
-    if (__ballot(w.pblk) == 0ull) return false; // nobody parked: every lane of the call is done
-    // ---- parked blocks: 3x3 heights -> candidate cells, all parked lanes together ----
-    if (w.pblk) {
-        WCOUNT(4);
-        w.pend = block_cells(f, rs, fx, fy, w.pc0, w.pr0, w.pfx, w.pfy, thi, loadh);
-        w.pblk = false;
-    }
+    if (__ballot(w.pend != 0u) == 0ull) return false; // nobody holds candidate cells: every lane of the call is done
     // ---- candidate cells, one per lane per round ----
     while (__ballot(w.pend != 0u) != 0ull) {
         WCOUNT(6);
@@ -521,8 +463,7 @@ __device__ __forceinline__ bool walk_subtree(const hf_dev_field &f, const Src &s
 // is visited because all its ancestors overlap that ray too.
 
 template <bool ANY>
-__device__ __forceinline__ void walk_packet(const hf_dev_field &f, const hf_lds_mips &s,
-                                            const hf_ray_state &rs, bool alive, bool coherent, bool fx, bool fy,
+__device__ __forceinline__ void walk_packet(const hf_dev_field &f, const hf_ray_state &rs, bool alive, bool coherent, bool fx, bool fy,
                                             hf_hit &best) {
     const hf_trav &r = rs.r;
     const int top = f.top;
@@ -597,25 +538,17 @@ __device__ __forceinline__ void walk_packet(const hf_dev_field &f, const hf_lds_
         WCOUNT(0);
         {
             hf_quad q;
-            {   // children boxes: from the LDS-staged top of the pyramid when they are in it
+            {   // children boxes: the two x-adjacent children of a row are one aligned 16-byte entry pair (hf_depth_off)
                 const uint32_t kd = (uint32_t) (top - (L - 1));
                 const uint32_t ix = X ^ (fxm >> L), iy = Y ^ (fym >> L);
                 const uint32_t base = hf_depth_off((int) kd) + ((2u * iy) << kd) + 2u * ix;
                 // the two x-adjacent children of a row are one aligned 16-byte entry pair (hf_depth_off); uniform
                 // address: LDS broadcast read for the staged depths, scalar-cache load beyond them
-                float4 c01, c23;
-#if HF_SHARED_LDS
-                if (base + (1u << kd) + 1u < HF_LDS_NODES) {
-                    c01 = *(const float4 *) &s.node[base];
-                    c23 = *(const float4 *) &s.node[base + (1u << kd)];
-                } else
-#endif
-                {
-                    // a scalar (uniform) global address: s_load through the scalar cache
-                    const uint32_t ub0 = (uint32_t) __builtin_amdgcn_readfirstlane((int) base);
-                    c01 = *(const float4 *) (mip + ub0);
-                    c23 = *(const float4 *) (mip + ub0 + (1u << kd));
-                }
+                // a scalar (uniform) global address: one cache line, broadcast to the wave (an LDS-staged copy of
+                // the top of the pyramid measured the same and is gone)
+                const uint32_t ub0 = (uint32_t) __builtin_amdgcn_readfirstlane((int) base);
+                const float4 c01 = *(const float4 *) (mip + ub0);
+                const float4 c23 = *(const float4 *) (mip + ub0 + (1u << kd));
                 q.lo[0] = c01.x; q.hi[0] = c01.y; q.lo[1] = c01.z; q.hi[1] = c01.w;
                 q.lo[2] = c23.x; q.hi[2] = c23.y; q.lo[3] = c23.z; q.hi[3] = c23.w;
             }
@@ -689,11 +622,8 @@ __device__ __forceinline__ void miss_si(hf_si_rec &si, v3 d, uint32_t flags) {
 #ifndef HF_EXP
 #define HF_EXP 0
 #endif
-#ifndef HF_SHARED_LDS
-#define HF_SHARED_LDS 0 // shared walk reads its boxes through the scalar cache (1: the staged depths from LDS)
-#endif
 #ifndef HF_TRACE_WAVES
-#define HF_TRACE_WAVES 5 // resident waves per SIMD = workgroups per CU of the traversal kernel (96 VGPRs)
+#define HF_TRACE_WAVES 6 // resident waves per SIMD = workgroups per CU of the traversal kernel (80 VGPRs)
 #endif
 #define HF_NUM_XCD 8u // work counters per launch, one per XCD (power of two)
 #define HF_COUNTER_STRIDE 16u // in counters: 128 bytes apart
@@ -755,8 +685,6 @@ __device__ __forceinline__ hf_si_dev load_si(hf_kargs_ptr ka) {
 template <int MODE>
 __global__ __launch_bounds__(HF_BLOCK, HF_TRACE_WAVES) void hf_trace_kernel(hf_trace_args a) {
     const hf_dev_field &f = a.f;
-    __shared__ hf_lds_mips s;
-    stage_mips(f, s);
     const unsigned lane = threadIdx.x & 63u;
     // Work distribution: the wavefront is cut into grabs of `grab` consecutive rays and the grabs into HF_NUM_XCD
     // contiguous bands, one per XCD, each with its own counter (a single counter serves ~80 fetches/us, which capped
@@ -847,7 +775,7 @@ __global__ __launch_bounds__(HF_BLOCK, HF_TRACE_WAVES) void hf_trace_kernel(hf_t
             bool alive;
             {
                 const hf_dev_field f0 = load_field(&ka->f); // to_object etc.
-                alive = act && setup_ray(f0, s.node[1], o, d, maxt, rs);
+                alive = act && setup_ray(f0, f0.mip[1], o, d, maxt, rs); // mip[1]: the global height range
             }
             const v3 dw = d; // world-space direction: wi of the record
             const uint64_t am = __ballot(alive);
@@ -867,7 +795,7 @@ __global__ __launch_bounds__(HF_BLOCK, HF_TRACE_WAVES) void hf_trace_kernel(hf_t
 #ifdef HF_TSTATS
                 const long long tb1 = clock64();
 #endif
-                walk_packet<MODE == 1>(f, s, rs, alive, coherent, fx0, fy0, best);
+                walk_packet<MODE == 1>(f, rs, alive, coherent, fx0, fy0, best);
 #ifdef HF_TSTATS
                 if (alive) { best.t = (float) (clock64() - tb0); best.v = (float) (tb1 - tb0); }
 #endif
