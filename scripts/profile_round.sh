@@ -1,9 +1,10 @@
 #!/bin/bash
-# usage (on the GPU box, via gpurun): scripts/profile_round.sh TAG
+# usage (on the GPU box, via gpurun): scripts/profile_round.sh TAG [SOURCE]   (SOURCE: commit the profile is taken at)
 # rocprofv3 kernel stats of the bench command + PMC traffic / instruction counters of the kernels, reduced to
 # small CSV files under gpurun_out/TAG/ (the rocpd databases are deleted: gpurun copies back at most 64 MiB).
 set -e
 TAG=${1:-prof}
+SRC=${2:-unknown}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
@@ -18,7 +19,8 @@ for C in FETCH_SIZE WRITE_SIZE; do
   python $R/scripts/rocpd_summary.py pmc $OUT/pmc_$C/run_results.db hf_ > $OUT/pmc_$C.csv
   rm -rf $OUT/pmc_$C
 done
-rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES -d $OUT/pmc_sq -o run -- python $R/scripts/prof_kernels.py --iters 1 fwd miss > $OUT/pmc_sq.log 2>&1
+python $R/scripts/make_traffic_json.py $OUT "$SRC" > $OUT/traffic.json
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -d $OUT/pmc_sq -o run -- python $R/scripts/prof_kernels.py --iters 1 fwd miss > $OUT/pmc_sq.log 2>&1
 python $R/scripts/rocpd_summary.py pmc $OUT/pmc_sq/run_results.db hf_trace > $OUT/pmc_sq.csv
 rm -rf $OUT/pmc_sq
 cd $R && python bench.py --steps 20 --warmup 3 > $OUT/bench_20steps.json
