@@ -367,7 +367,7 @@ __device__ __forceinline__ bool walk_round(const hf_dev_field &f, const Src &src
                                            float &thi, hf_hit &best, hf_walk &w) {
     auto loadh = [&src](int i, int j) { return src.height(i, j); };
     bool hit_any = false;
-    // ---- walk until this lane reaches a level-1 node (parks on it) or has exhausted the subtree ----
+    // ---- walk until this lane holds candidate cells or has exhausted the subtree ----
     while (!w.fin && w.pend == 0u) {
         WCOUNT(3);
         if (w.cur == 0u) {
@@ -613,7 +613,7 @@ __device__ __forceinline__ void miss_si(hf_si_rec &si, v3 d, uint32_t flags) {
     si.wi = neg3(d);
 }
 
-#define HF_GRAB 512 // most rays a wave takes from the work counter per fetch (hf_grab_for)
+#define HF_GRAB 256 // most rays a wave takes from the work counter per fetch (hf_grab_for); 512 before the per-XCD counters
 // Scratch block of one trace launch (zeroed by hf_launch_trace): the per-XCD work counters.
 #define HF_SCR_BYTES 1024
 #ifndef HF_DIST
