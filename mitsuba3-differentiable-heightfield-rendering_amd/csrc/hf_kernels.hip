@@ -1,7 +1,7 @@
 // hf_kernels.hip -- gfx950 kernels of libhf + their launchers.
 //
 //   hf_mip_level1_kernel / hf_mip_reduce_kernel   min/max mip pyramid
-//   hf_shear_kernel                                sheared bounds of the fine levels (hf_device.h)
+//   hf_shear_kernel / hf_shear_minmax_kernel       node records of every level 1..top (hf_device.h)
 //   hf_trace_kernel<MODE>                          hierarchical min/max-mip traversal:
 //        MODE 0 closest hit  -> PreliminaryIntersection   (row a1)
 //        MODE 1 any hit      -> ray_test                   (row a2)
@@ -12,20 +12,20 @@
 //
 // Traversal = depth-first walk of the implicit quadtree over the cells, children in
 // front-to-back order (the grid is mirrored so the ray direction is non-negative on
-// both axes: "order space").  One visit of an inner node fetches the (min z, max z)
-// boxes of its 4 children and keeps those the *fat* ray segment [0,t_hi] overlaps; a
-// level-1 node fetches its 3x3 heights and yields the cells whose two triangles are
-// then tested.  On the fine levels (2..HF_SHEAR_TOP, and the 2x2-cell blocks) the boxes are
-// sheared about a plane through the node's corner heights, which is what makes them tight on
-// slopes.  Pending children live in 4-bit-per-level mask stacks held in registers.
+// both axes: "order space").  One visit of an inner node fetches its record -- a plane through
+// the node's corner heights and, per child, the range of (z - plane) over the child: "sheared
+// bounds", tight on slopes; the zero plane with plain min/max above level HF_SHEAR_TOP -- and keeps
+// the children the *fat* ray segment [0,t_hi] overlaps; the children of a level-1 node are
+// cells, whose two triangles are then tested.  Pending children live in 4-bit-per-level mask
+// stacks held in registers.
 // The 64 rays of a coherent wave (primary rays: one pixel's samples) share the walk of
-// the upper levels -- node coordinates, masks and stack are wave-uniform and live in
-// SGPRs, a child is entered when __ballot says any lane overlaps it -- and nodes of
+// the upper levels -- node coordinates, masks and stack are wave-uniform and pinned to
+// SGPRs (readfirstlane), a child is entered when __ballot says any lane overlaps it -- and nodes of
 // level HF_SUBTREE_LEVEL are handed to the per-lane walk; an incoherent wave hands the
-// root to every lane.  The per-lane walk is "while-while": lanes park on candidate cells
-// and the two-triangle test runs converged, one cell per lane per round.  The visited
-// set is a conservative superset of the cells the ray can hit; the per-triangle test and
-// the tie rule are order independent, so the result equals the brute force's.
+// root to every lane.  The per-lane walk runs in converged rounds: lanes walk until they hold
+// candidate cells, and the two-triangle test runs for all of them together, one cell per lane per
+// round.  The visited set is a conservative superset of the cells the ray can hit; the
+// per-triangle test and the tie rule are order independent, so the result equals the brute force's.
 #include "hf_device.h"
 #include "hf_launch.h"
 
@@ -542,8 +542,6 @@ __device__ __forceinline__ void walk_packet(const hf_dev_field &f, const hf_ray_
                 const uint32_t kd = (uint32_t) (top - (L - 1));
                 const uint32_t ix = X ^ (fxm >> L), iy = Y ^ (fym >> L);
                 const uint32_t base = hf_depth_off((int) kd) + ((2u * iy) << kd) + 2u * ix;
-                // the two x-adjacent children of a row are one aligned 16-byte entry pair (hf_depth_off); uniform
-                // address: LDS broadcast read for the staged depths, scalar-cache load beyond them
                 // a scalar (uniform) global address: one cache line, broadcast to the wave (an LDS-staged copy of
                 // the top of the pyramid measured the same and is gone)
                 const uint32_t ub0 = (uint32_t) __builtin_amdgcn_readfirstlane((int) base);
@@ -616,12 +614,6 @@ __device__ __forceinline__ void miss_si(hf_si_rec &si, v3 d, uint32_t flags) {
 #define HF_GRAB 256 // most rays a wave takes from the work counter per fetch (hf_grab_for); 512 before the per-XCD counters
 // Scratch block of one trace launch (zeroed by hf_launch_trace): the per-XCD work counters.
 #define HF_SCR_BYTES 1024
-#ifndef HF_DIST
-#define HF_DIST 2
-#endif
-#ifndef HF_EXP
-#define HF_EXP 0
-#endif
 #ifndef HF_TRACE_WAVES
 #define HF_TRACE_WAVES 6 // resident waves per SIMD = workgroups per CU of the traversal kernel (80 VGPRs)
 #endif
@@ -640,7 +632,7 @@ struct hf_trace_args {
     uint32_t flags;
     uint32_t grab; // rays per fetch, a multiple of 64
     unsigned long long *counter;
-    unsigned long long n_grabs, band; // ceil(n / grab) grabs, in HF_NUM_XCD bands of `band` grabs
+    unsigned long long n_grabs; // ceil(n / grab)
 };
 
 // member-wise copy out of the kernarg segment (constant address space)
@@ -686,11 +678,12 @@ template <int MODE>
 __global__ __launch_bounds__(HF_BLOCK, HF_TRACE_WAVES) void hf_trace_kernel(hf_trace_args a) {
     const hf_dev_field &f = a.f;
     const unsigned lane = threadIdx.x & 63u;
-    // Work distribution: the wavefront is cut into grabs of `grab` consecutive rays and the grabs into HF_NUM_XCD
-    // contiguous bands, one per XCD, each with its own counter (a single counter serves ~80 fetches/us, which capped
-    // the rays that only stream at half the memory bandwidth; eight addresses are served in parallel).  A wave pulls
-    // from the band of the XCD it runs on -- neighbouring pixels, hence neighbouring height / mip lines, stay in one
-    // L2 -- and moves on to the next band when its own is exhausted, so all XCDs finish together whatever the bands cost.
+    // Work distribution: the wavefront is cut into grabs of `grab` consecutive rays; XCD x owns grabs x, x + 8, ...
+    // and hands them out through its own counter (a single counter serves ~80 fetches/us, which capped the rays
+    // that only stream at half the memory bandwidth; eight addresses are served in parallel).  A wave pulls from the
+    // counter of the XCD it runs on and moves on to the next XCD's when its own is exhausted, so all XCDs finish
+    // together.  Grab numbers map to rays from the middle of the wavefront outwards (even: towards the end, odd:
+    // towards the front): stream-only and traversal regions of a rendered wavefront then overlap in time.
     // (launch constants are read from the kernarg segment where they are needed -- see below -- so that the only
     // scalar state alive across a walk is the band, the current grab and the position in it)
     unsigned xc, tried = 0;
@@ -702,32 +695,11 @@ __global__ __launch_bounds__(HF_BLOCK, HF_TRACE_WAVES) void hf_trace_kernel(hf_t
         asm volatile("" : "+s"(kg));
         unsigned long long *counter = kg->counter;
         const unsigned grab = kg->grab;
-        const unsigned long long n_grabs = kg->n_grabs, band = kg->band;
+        const unsigned long long n_grabs = kg->n_grabs;
         unsigned long long g = 0;
         if (lane == 0) g = atomicAdd(counter + (size_t) xc * HF_COUNTER_STRIDE, 1ull);
         g = ((unsigned long long) (uint32_t) __builtin_amdgcn_readfirstlane((int) (g >> 32)) << 32) |
             (unsigned long long) (uint32_t) __builtin_amdgcn_readfirstlane((int) (g & 0xffffffffull));
-#if HF_DIST == 0
-        const unsigned long long b0 = band * xc;
-        const unsigned long long bn = b0 >= n_grabs ? 0ull : (n_grabs - b0 < band ? n_grabs - b0 : band); // grabs of this band
-        if (g >= bn) { // band exhausted: steal from the next one; done when all have been seen exhausted
-            if (++tried == HF_NUM_XCD) break;
-            xc = (xc + 1u) & (HF_NUM_XCD - 1u);
-            continue;
-        }
-        const unsigned long long base = (b0 + g) * grab;
-#elif HF_DIST == 1
-        // interleaved: XCD x owns grabs x, x+8, x+16, ...
-        const unsigned long long gg = g * HF_NUM_XCD + xc;
-        if (gg >= n_grabs) {
-            if (++tried == HF_NUM_XCD) break;
-            xc = (xc + 1u) & (HF_NUM_XCD - 1u);
-            continue;
-        }
-        const unsigned long long base = gg * grab;
-        (void) band;
-#else
-        // interleaved + two fronts: even grabs walk from the middle to the end, odd ones from the middle to the front
         const unsigned long long gg = g * HF_NUM_XCD + xc;
         if (gg >= n_grabs) {
             if (++tried == HF_NUM_XCD) break;
@@ -735,8 +707,6 @@ __global__ __launch_bounds__(HF_BLOCK, HF_TRACE_WAVES) void hf_trace_kernel(hf_t
             continue;
         }
         const unsigned long long base = ((gg & 1ull) ? (n_grabs >> 1) - 1ull - (gg >> 1) : (n_grabs >> 1) + (gg >> 1)) * grab;
-        (void) band;
-#endif
         // the ray of the batch in flight: requested one batch ahead (see below)
         v3 o = mk3(0.f, 0.f, 0.f), d = o;
         float maxt = 0.f;
@@ -828,10 +798,6 @@ __global__ __launch_bounds__(HF_BLOCK, HF_TRACE_WAVES) void hf_trace_kernel(hf_t
                 if (MODE == 2) {
                     hf_si_rec si;
                     const uint32_t flags = ka->flags;
-#if HF_EXP == 1   // experiment: no SI computation (records of hits are garbage)
-                    miss_si(si, dw, flags);
-                    si.t = best.hit ? best.t : si.t;
-#else
                     if (best.hit) {
                         // the origin is only needed by a hit: read again (an L2 hit) rather than held across the walk
                         const hf_rays_dev rp = load_rays(ka);
@@ -840,21 +806,8 @@ __global__ __launch_bounds__(HF_BLOCK, HF_TRACE_WAVES) void hf_trace_kernel(hf_t
                         compute_si(fl, ow, dw, best.t, best.u, best.v, best.prim, flags, si);
                     }
                     else          miss_si(si, dw, flags);
-#endif
-#if HF_EXP == 2   // experiment: SI computed, only one row stored
-                    {
-                        const hf_si_dev sio = load_si(ka);
-                        st(sio.t, ub, lo, si.t + si.p.x + si.n.y + si.dp_du.z + si.dp_dv.x + si.uv0 + si.sh_n.z);
-                    }
-#elif HF_EXP == 3 // experiment: records stored for the rays that hit only
-                    if (best.hit) {
-                        const hf_si_dev sio = load_si(ka);
-                        store_si(sio, ub, lo, si, flags);
-                    }
-#else
                     const hf_si_dev sio = load_si(ka); // all row pointers at once (wide scalar loads), then the stores
                     store_si(sio, ub, lo, si, flags);
-#endif
                 }
             }
         }
@@ -921,7 +874,7 @@ void hf_launch_trace(int mode, const hf_dev_field &f, size_t n, const hf_rays_t 
     hf_trace_args a;
     a.f = f; a.n = n; a.rays = r; a.active = active; a.pi = p; a.hit_out = hit; a.sio = sd; a.flags = flags;
     a.counter = (unsigned long long *) scratch; a.grab = grab;
-    a.n_grabs = waves; a.band = (waves + HF_NUM_XCD - 1) / HF_NUM_XCD;
+    a.n_grabs = waves;
     if (mode == 0)
         hipLaunchKernelGGL(hf_trace_kernel<0>, grid, block, 0, stream, a);
     else if (mode == 1)

@@ -40,7 +40,21 @@ for sc in range(scenes):
     o = np.repeat(o, 64, 1) + rng.uniform(-1, 1, (3, npix * 64)) * np.exp(rng.uniform(np.log(1e-4), np.log(3e-2)))
     d = np.repeat(dirs, 64, 1) * (1 + rng.uniform(-1e-3, 1e-3, (1, npix * 64)))
     pk = np.concatenate([o, d, np.full((1, npix * 64), np.inf)]).astype(np.float32)
+    # axis-aligned rays with POSITIVE and NEGATIVE zero direction components (1/(-0) = -inf once flipped the walk's
+    # slab tests): object-space rays with one or two zeroed components, half of the zeros negated
+    nz = max(64, nrays // 16)
+    az = common.random_rays(nz, rng, mh)
+    kill = rng.integers(0, 3, nz)
+    for c in range(3):
+        az[3 + c, kill == c] = 0.0
+    az[3 + (kill + 1) % 3, np.arange(nz)] = np.where(rng.uniform(size=nz) < 0.4, 0.0, az[3 + (kill + 1) % 3, np.arange(nz)])
+    zero = az[3:6] == 0
+    az[3:6][zero & (rng.uniform(size=zero.shape) < 0.5)] = np.float32(-0.0)
+    az[3:6, (az[3:6] == 0).all(0)] = np.array([[0.0], [-0.0], [-1.0]], np.float32)    # never a null direction
+    parts.append(az)
     r = common.to_world_rays(np.concatenate([pk] + parts, 1), tw)
+    if tw is None:   # (an affine to_world mixes the components; keep the signed zeros exact where it is the identity)
+        r[3:6, -nz:] = az[3:6]
     rt = torch.from_numpy(r).cuda()
     ray = hf_amd.Ray3f(rt[0:3].contiguous(), rt[3:6].contiguous(), rt[6].contiguous())
     pi = f_g.ray_intersect_preliminary(ray)
