@@ -568,6 +568,97 @@ done:;
 #endif
 }
 
+// wave-wide minimum / maximum of an unsigned value, result scalar (DPP within rows of 16, readlane across rows);
+// every lane of the wave must call these
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+    uint32_t x = v;
+    x = min(x, (uint32_t) __builtin_amdgcn_update_dpp(0, (int) x, 0xB1, 0xF, 0xF, true));  // quad_perm [1,0,3,2]
+    x = min(x, (uint32_t) __builtin_amdgcn_update_dpp(0, (int) x, 0x4E, 0xF, 0xF, true));  // quad_perm [2,3,0,1]
+    x = min(x, (uint32_t) __builtin_amdgcn_update_dpp(0, (int) x, 0x141, 0xF, 0xF, true)); // row_half_mirror
+    x = min(x, (uint32_t) __builtin_amdgcn_update_dpp(0, (int) x, 0x140, 0xF, 0xF, true)); // row_mirror
+    const uint32_t a = (uint32_t) __builtin_amdgcn_readlane((int) x, 0), b = (uint32_t) __builtin_amdgcn_readlane((int) x, 16);
+    const uint32_t c = (uint32_t) __builtin_amdgcn_readlane((int) x, 32), d = (uint32_t) __builtin_amdgcn_readlane((int) x, 48);
+    return min(min(a, b), min(c, d));
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) { return ~wave_min_u32(~v); }
+
+// Coherent wave, upper levels by ROW SWEEP: instead of descending the pyramid from the root (a chain of dependent
+// node fetches: fetch -> test four children -> ballots -> next fetch, 42 % of a traversing wave's time), the nodes
+// of the hand-off level HF_SUBTREE_LEVEL that any lane's fat ray can touch are enumerated geometrically -- row by
+// row of that level in order space (front to back: a monotone ray that visits (i,j) before (i',j') has j' > j, or
+// j' = j and i' > i), the row's node range from the lanes' x extents inside the row slab (wave min / max) -- and each
+// enumerated node is tested per lane against its (min z, max z) box with the same arithmetic child_mask uses.
+// The node addresses do not depend on fetched data, and one node costs one box test instead of a share of a
+// four-child visit per level.  The enumeration is a superset (slack below); the per-lane test decides.
+template <bool ANY>
+__device__ __forceinline__ void walk_rows(const hf_dev_field &f, const hf_ray_state &rs, bool alive, bool fx, bool fy,
+                                          hf_hit &best) {
+    const hf_trav &r = rs.r;
+    const int top = f.top;
+    const uint32_t kd = (uint32_t) (top - HF_SUBTREE_LEVEL), nn = 1u << kd; // depth of the hand-off level, nodes per side
+    const float S = (float) (1u << HF_SUBTREE_LEVEL), iS = 1.0f / S, lim = (float) nn - 0.5f;
+    const float2 *__restrict__ lvl = f.mip + hf_depth_off((int) kd);
+    float thi = alive ? rs.thi : -1.f; // dead lanes overlap nothing
+    // (per-lane values that are cheap to form are recomputed where they are used rather than held in registers
+    // across the per-lane walks: the kernel runs at 80 VGPRs)
+    hf_src_global src;
+    src.mip = f.mip; src.shear = f.shear; src.h = f.h; src.top = f.top; src.W = f.W;
+    const uint32_t lfxm = rs.fx ? ((1u << top) - 1u) : 0u, lfym = rs.fy ? ((1u << top) - 1u) : 0u;
+    // rows the wave's rays can touch: [gy - m, gy + m + t_hi dy] per lane, widened by the slack of this estimate
+    uint32_t jmin, jmax;
+    {
+        const float dyo = __builtin_fabsf(rs.od.y) * (0.5f * (float) (f.H - 1)); // cells per unit t, order space
+        const float ya = r.gyp - 1e-3f, yb = __builtin_fmaf(thi, dyo, r.gym);
+        const float yb2 = yb + 1e-3f + 1e-6f * yb;
+        jmin = wave_min_u32(alive ? (uint32_t) fminf(fmaxf(ya * iS, 0.f), lim) : 0xFFFFFFFFu);
+        jmax = wave_max_u32(alive ? (uint32_t) fminf(fmaxf(yb2 * iS, 0.f), lim) : 0u);
+    }
+    for (uint32_t j = jmin; j <= jmax; ++j) { // wave-uniform
+        const float fY = (float) j * S;
+        // this lane's parameter interval inside the row slab (fat in y), clipped to [0, t_hi]; v_max / v_min drop
+        // the NaN of 0 * inf (axis-parallel ray exactly on a slab plane)
+        const float ty0 = (fY - r.gym) * r.idy, ty1 = (fY + S - r.gyp) * r.idy;
+        const float t0 = fmaxf(ty0, 0.f), t1 = fminf(ty1, thi);
+        const bool in_row = t0 <= t1;
+        if (__ballot(in_row) == 0ull) {
+            // nobody is inside this row; done when nobody can reach a later one either
+            if (__ballot(ty1 <= thi) == 0ull) break;
+            continue;
+        }
+        uint32_t imin, imax;
+        {
+            const float dxo = __builtin_fabsf(rs.od.x) * (0.5f * (float) (f.W - 1));
+            const float xa = __builtin_fmaf(t0, dxo, r.gxp) - 1e-3f, xb = __builtin_fmaf(t1, dxo, r.gxm);
+            const float xb2 = xb + 1e-3f + 1e-6f * xb;
+            imin = wave_min_u32(in_row ? (uint32_t) fminf(fmaxf(xa * iS, 0.f), lim) : 0xFFFFFFFFu);
+            imax = wave_max_u32(in_row ? (uint32_t) fminf(fmaxf(xb2 * iS, 0.f), lim) : 0u);
+        }
+        const uint32_t aj = fy ? nn - 1u - j : j;
+        for (uint32_t i = imin; i <= imax; ++i) { // wave-uniform
+            WCOUNT(1);
+            const uint32_t ai = fx ? nn - 1u - i : i;
+            const float2 box = lvl[(aj << kd) + ai]; // uniform address: one line, broadcast
+            const float fX = (float) i * S, fYi = (float) j * S;
+            const float xlo = (fX - r.gxm) * r.idx, xhi = (fX + S - r.gxp) * r.idx;
+            const float ylo = (fYi - r.gym) * r.idy, yhi = (fYi + S - r.gyp) * r.idy;
+            const float u0 = fmaxf(fmaxf(xlo, ylo), 0.f), u1 = fminf(fminf(xhi, yhi), thi);
+            const float za = __builtin_fmaf(u0, r.dz, r.gz), zb = __builtin_fmaf(u1, r.dz, r.gz);
+            const bool mine = (u0 <= u1) & (fminf(za, zb) - r.mz <= box.y) & (fmaxf(za, zb) + r.mz >= box.x);
+            if (__ballot(mine) == 0ull) continue;
+            WCOUNT(2);
+            if (mine) {
+                const bool h = walk_subtree<ANY>(f, src, rs, r, rs.fx, rs.fy, lfxm, lfym, i, j, HF_SUBTREE_LEVEL, thi, best);
+                if (ANY && h) thi = -1.f;
+            }
+        }
+        if (ANY && __ballot(thi >= 0.f) == 0ull) break;
+    }
+#ifdef HF_WSTATS
+    if (alive) { const uint32_t *c = wcnt_base(); best.hit = true; best.t = (float) c[0] + 1024.f * (float) c[1] + 1048576.f * (float) c[2];
+        best.u = (float) c[3] + 4096.f * (float) c[4]; best.v = (float) c[5] + 4096.f * (float) c[6]; }
+#endif
+}
+
 struct hf_rays_dev {
     const float *o[3];
     const float *d[3];
@@ -614,6 +705,12 @@ __device__ __forceinline__ void miss_si(hf_si_rec &si, v3 d, uint32_t flags) {
 #define HF_GRAB 256 // most rays a wave takes from the work counter per fetch (hf_grab_for); 512 before the per-XCD counters
 // Scratch block of one trace launch (zeroed by hf_launch_trace): the per-XCD work counters.
 #define HF_SCR_BYTES 1024
+#ifndef HF_ROW_SWEEP
+#define HF_ROW_SWEEP 1
+#endif
+#ifndef HF_TRACE_WAVES_FUSED
+#define HF_TRACE_WAVES_FUSED 5 // ... of the fused mode: its surface-interaction tail needs ~100 registers (6 waves: 30 spills, slower)
+#endif
 #ifndef HF_TRACE_WAVES
 #define HF_TRACE_WAVES 6 // resident waves per SIMD = workgroups per CU of the traversal kernel (80 VGPRs)
 #endif
@@ -675,7 +772,7 @@ __device__ __forceinline__ hf_si_dev load_si(hf_kargs_ptr ka) {
 // counter (zeroed on the stream before the launch), so expensive image regions are
 // spread over all CUs whatever their position in the wavefront.
 template <int MODE>
-__global__ __launch_bounds__(HF_BLOCK, HF_TRACE_WAVES) void hf_trace_kernel(hf_trace_args a) {
+__global__ __launch_bounds__(HF_BLOCK, (MODE == 2 ? HF_TRACE_WAVES_FUSED : HF_TRACE_WAVES)) void hf_trace_kernel(hf_trace_args a) {
     const hf_dev_field &f = a.f;
     const unsigned lane = threadIdx.x & 63u;
     // Work distribution: the wavefront is cut into grabs of `grab` consecutive rays; XCD x owns grabs x, x + 8, ...
@@ -765,7 +862,20 @@ __global__ __launch_bounds__(HF_BLOCK, HF_TRACE_WAVES) void hf_trace_kernel(hf_t
 #ifdef HF_TSTATS
                 const long long tb1 = clock64();
 #endif
+#if HF_ROW_SWEEP
+                if (coherent && f.top > HF_SUBTREE_LEVEL) {
+                    walk_rows<MODE == 1>(f, rs, alive, fx0, fy0, best);
+                } else if (alive) {
+                    // incoherent wave (or a grid smaller than one hand-off node): every live lane walks from the root
+                    hf_src_global src;
+                    src.mip = f.mip; src.shear = f.shear; src.h = f.h; src.top = f.top; src.W = f.W;
+                    const uint32_t lfxm = rs.fx ? ((1u << f.top) - 1u) : 0u, lfym = rs.fy ? ((1u << f.top) - 1u) : 0u;
+                    float thi = rs.thi;
+                    (void) walk_subtree<MODE == 1>(f, src, rs, rs.r, rs.fx, rs.fy, lfxm, lfym, 0u, 0u, f.top, thi, best);
+                }
+#else
                 walk_packet<MODE == 1>(f, rs, alive, coherent, fx0, fy0, best);
+#endif
 #ifdef HF_TSTATS
                 if (alive) { best.t = (float) (clock64() - tb0); best.v = (float) (tb1 - tb0); }
 #endif
@@ -844,7 +954,7 @@ static hf_si_dev to_dev(const hf_si_t *s) {
 // rays that only stream), fewer for small ones so that every resident wave gets several fetches --
 // a fetch of 512 traversing rays is ~0.4 ms of work, the whole launch for a 4 M-ray wavefront.
 static uint32_t hf_grab_for(size_t n) {
-    const size_t resident = 256 * 4 * HF_TRACE_WAVES; // waves the launch keeps on the chip
+    const size_t resident = 256 * 4 * HF_TRACE_WAVES; // waves the launch keeps on the chip (about)
     size_t g = (n / (resident * 4) + 63) / 64 * 64; // ~4 fetches per wave
     if (g < 64) g = 64;
     if (g > HF_GRAB) g = HF_GRAB;
@@ -869,7 +979,8 @@ void hf_launch_trace(int mode, const hf_dev_field &f, size_t n, const hf_rays_t 
     const hf_rays_dev r = to_dev(rays);
     const uint32_t grab = hf_grab_for(n);
     size_t waves = (n + grab - 1) / grab, blocks = (waves + 3) / 4;
-    if (blocks > 256 * HF_TRACE_WAVES) blocks = 256 * HF_TRACE_WAVES; // the resident set: HF_TRACE_WAVES workgroups per CU
+    const size_t per_cu = mode == 2 ? HF_TRACE_WAVES_FUSED : HF_TRACE_WAVES;
+    if (blocks > 256 * per_cu) blocks = 256 * per_cu; // the resident set: that many workgroups per CU
     const dim3 grid((unsigned) blocks), block(HF_BLOCK);
     hf_trace_args a;
     a.f = f; a.n = n; a.rays = r; a.active = active; a.pi = p; a.hit_out = hit; a.sio = sd; a.flags = flags;

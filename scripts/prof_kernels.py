@@ -70,6 +70,11 @@ if any(k.startswith("alive") for k in a.kinds):
     fn["alive_fwd"] = lambda: _capi.check(lib.hf_ray_intersect(shape._h, Ra, C.byref(a_s), flags, None, C.byref(pi_s), C.byref(si_s), st))
     fn["alive_prelim"] = lambda: _capi.check(lib.hf_ray_intersect_preliminary(shape._h, Ra, C.byref(a_s), None, C.byref(pi_s), st))
     nrays.update({"alive_fwd": Ra, "alive_prelim": Ra})
+for nm, org in (("fwd_ymajor", (0.15, 2.6, 0.9)), ("fwd_xmajor", (2.6, 0.15, 0.9)), ("fwd_steep", (0.3, 0.2, 3.0))):
+    if nm in a.kinds:   # other view directions: grazing along y / along x (long paths through the grid), steep from above
+        rr = hf_amd.workload.ortho_rays(a.film, a.film, a.spp, dev, origin=org, target=(0.0, 0.0, 0.1), scale=(1.3, 1.3, 1.0))
+        rs_ = shape._rays_struct(rr[0:3], rr[3:6], rr[6])
+        fn[nm] = (lambda rs_=rs_, rr=rr: _capi.check(lib.hf_ray_intersect(shape._h, R, C.byref(rs_), flags, None, C.byref(pi_s), C.byref(si_s), st)))
 if "reparam" in a.kinds:
     # backward of reparameterize_ray (4 auxiliary rays per primary ray: 8 fused traces + 8 weight kernels + 4 adjoints)
     hfp = shape.heightfield.requires_grad_(True)
