@@ -106,3 +106,47 @@ def test_gpu_follow_shape_ray_gradients(hf, W, H):
         assert np.allclose(row("p", k)[0], 0, atol=1e-6) and np.allclose(row("p", k)[1], 0, atol=1e-6)
     go, gd = row("t", 0)
     assert np.allclose(go, [0, 0, -1], atol=1e-5) and abs(gd[2] - (-10.0)) < 1e-4
+
+
+# ---- src/render/tests/test_mesh.py:458-531 (test15, forward mode w.r.t. the vertex positions), the part a height
+# grid can express: translating every vertex along z == lifting every height (max_height = 1, to_world = I):
+#     ray (-0.2,-0.3,-10) -> +z:   d si.t / dz = 1,   d si.p / dz = [0,0,1];   uv does not depend on z.
+# Forward mode over a uniform lift = the SUM over all texels of one reverse-mode row.
+def _ray15():
+    return np.array([[-0.2], [-0.3], [-10.0], [0.0], [0.0], [1.0], [np.inf]], np.float32)
+
+
+def _check_lift_answers(lift):
+    assert abs(lift("t", 0) - 1.0) < 1e-5
+    assert np.allclose([lift("p", k) for k in range(3)], [0, 0, 1], atol=1e-5)
+    assert np.allclose([lift("uv", k) for k in range(2)], [0, 0], atol=1e-6)
+
+
+@pytest.mark.parametrize("W,H", GRIDS)
+def test_oracle_uniform_lift_known_answers(oracle, W, H):
+    f = oracle.OracleField(np.zeros((H, W), np.float32), 1.0)
+    r = _ray15()
+    t, u, v, prim = f.ray_intersect_preliminary(r)
+    assert abs(t[0] - 10.0) < 1e-6
+
+    def lift(field, comp):
+        g = {field: np.zeros((dict(oracle.GRAD_FIELDS)[field], 1), np.float32)}
+        g[field][comp, 0] = 1.0
+        return float(f.adjoint(r, t, u, v, prim, g).sum())
+    _check_lift_answers(lift)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("W,H", GRIDS)
+def test_gpu_uniform_lift_known_answers(hf, W, H):
+    import torch
+    r = torch.from_numpy(_ray15()).cuda()
+
+    def lift(field, comp):
+        h = torch.zeros(H, W, device="cuda", requires_grad=True)
+        shape = hf.Heightfield(heightfield=h, max_height=1.0)
+        si = shape.ray_intersect(hf.Ray3f(r[0:3], r[3:6], r[6]), hf.RayFlags.All)
+        out = getattr(si, field)
+        (out[comp] if out.dim() == 2 else out).sum().backward()
+        return float(h.grad.sum())
+    _check_lift_answers(lift)
