@@ -705,6 +705,12 @@ __device__ __forceinline__ void miss_si(hf_si_rec &si, v3 d, uint32_t flags) {
 #define HF_GRAB 256 // most rays a wave takes from the work counter per fetch (hf_grab_for); 512 before the per-XCD counters
 // Scratch block of one trace launch (zeroed by hf_launch_trace): the per-XCD work counters.
 #define HF_SCR_BYTES 1024
+#ifndef HF_COH_WINDOW
+#define HF_COH_WINDOW 32.f // a wave is coherent when its entry points are within this many cells of the first live lane's
+#endif
+#ifndef HF_COH_DIR
+#define HF_COH_DIR 0.05f   // ... and the xy direction ratios within this relative distance
+#endif
 #ifndef HF_ROW_SWEEP
 #define HF_ROW_SWEEP 1
 #endif
@@ -854,9 +860,9 @@ __global__ __launch_bounds__(HF_BLOCK, (MODE == 2 ? HF_TRACE_WAVES_FUSED : HF_TR
                 const float gx0 = __shfl(rs.gx, src), gy0 = __shfl(rs.gy, src);
                 const float ux = rs.r.idy, uy = rs.r.idx; // direction ratio proxy: compare idx/idy cross products
                 const float ux0 = __shfl(ux, src), uy0 = __shfl(uy, src);
-                const bool near = (rs.fx == fx0) & (rs.fy == fy0) & (__builtin_fabsf(rs.gx - gx0) <= 32.f) &
-                                  (__builtin_fabsf(rs.gy - gy0) <= 32.f) &
-                                  (__builtin_fabsf(ux * uy0 - uy * ux0) <= 0.05f * __builtin_fabsf(ux * uy0));
+                const bool near = (rs.fx == fx0) & (rs.fy == fy0) & (__builtin_fabsf(rs.gx - gx0) <= HF_COH_WINDOW) &
+                                  (__builtin_fabsf(rs.gy - gy0) <= HF_COH_WINDOW) &
+                                  (__builtin_fabsf(ux * uy0 - uy * ux0) <= HF_COH_DIR * __builtin_fabsf(ux * uy0));
                 const bool coherent = __ballot(alive && !near) == 0ull;
                 // incoherent wave: the shared walk degenerates to handing the root to every live lane
 #ifdef HF_TSTATS
@@ -1042,17 +1048,92 @@ __device__ __forceinline__ uint32_t wave_or(uint32_t v) {
                        __builtin_amdgcn_readlane(x, 32) | __builtin_amdgcn_readlane(x, 48));
 }
 
+// ---------------------------------------------------------------------------------
+// Warped-area reparameterisation (include/hf.h; reparam.py:10-123,224-333): per-sample kernels
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ void tea32(uint32_t v0, uint32_t v1, uint32_t &o0, uint32_t &o1) { // random.h:76-91
+    uint32_t sum = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        sum += 0x9e3779b9u;
+        v0 += ((v1 << 4) + 0xa341316cu) ^ (v1 + sum) ^ ((v1 >> 5) + 0xc8013ea4u);
+        v1 += ((v0 << 4) + 0xad90777du) ^ (v0 + sum) ^ ((v0 >> 5) + 0x7e95761eu);
+    }
+    o0 = v0; o1 = v1;
+}
+
+struct hf_aux_sample {
+    v3 omega;     // square_to_von_mises_fisher(sample, kappa), xy negated on the flipped half of a pair
+    float sy;     // sample.y
+    v3 fs, ft;    // Frame3f(d): s, t (n = d)
+};
+__device__ __forceinline__ void aux_sample(const hf_reparam_args &a, size_t i, v3 d, hf_aux_sample &q) {
+    const uint32_t pair = a.antithetic ? (a.k >> 1) : a.k;
+    uint32_t r0, r1;
+    tea32(a.seed + pair, (uint32_t) i, r0, r1);
+    const float sx = (float) (r0 >> 9) * (1.0f / 8388608.0f), sy = (float) (r1 >> 9) * (1.0f / 8388608.0f);
+    // warp.h:557-566
+    const float syc = fmaxf(1.f - sy, 1e-6f);
+    const float cos_theta = 1.f + logf(__builtin_fmaf(1.f - syc, expf(-2.f * a.kappa), syc)) / a.kappa;
+    float sn, cs;
+    sincosf(6.283185307179586f * sx, &sn, &cs);
+    const float sin_theta = __builtin_sqrtf(fmaxf(1.f - cos_theta * cos_theta, 0.f));
+    const bool flip = a.antithetic && ((a.k & 1u) == 0u); // reparam.py:83-85,189
+    q.omega = mk3(flip ? -(cs * sin_theta) : cs * sin_theta, flip ? -(sn * sin_theta) : sn * sin_theta, cos_theta);
+    q.sy = sy;
+    coordinate_system(d, q.fs, q.ft);
+}
+// Frame3f::to_world (frame.h:39-41)
+__device__ __forceinline__ v3 frame_to_world(const hf_aux_sample &q, v3 n, v3 v) {
+    return mk3(__builtin_fmaf(n.x, v.z, __builtin_fmaf(q.ft.x, v.y, q.fs.x * v.x)),
+               __builtin_fmaf(n.y, v.z, __builtin_fmaf(q.ft.y, v.y, q.fs.y * v.x)),
+               __builtin_fmaf(n.z, v.z, __builtin_fmaf(q.ft.z, v.y, q.fs.z * v.x)));
+}
+
+// harmonic weight of one auxiliary sample and its gradient w.r.t. the sampled direction (reparam.py:103-121)
+__device__ __forceinline__ void reparam_weight(const hf_reparam_args &a, const hf_aux_sample &q, v3 d, float B,
+                                               float &w, v3 &dw) {
+    const float inv_vmf = 1.0f / __builtin_fmaf(q.sy, expf(-2.f * a.kappa), 1.f - q.sy);
+    const float w_denom = inv_vmf - 1.f + B;
+    const float w_rcp = (w_denom > 1e-4f) ? 1.0f / w_denom : 0.f;
+    w = powf(w_rcp, a.exponent) * inv_vmf;
+    const float tmp1 = fminf(fmaxf(inv_vmf * w * w_rcp * a.kappa * a.exponent, -1e10f), 1e10f);
+    const v3 tmp2 = frame_to_world(q, d, mk3(q.omega.x, q.omega.y, 0.f));
+    dw = mk3(tmp1 * tmp2.x, tmp1 * tmp2.y, tmp1 * tmp2.z);
+}
+// gradient w.r.t. this sample's V_direct: backward of direction = normalize(d + V/Z),
+// divergence = (div - <V/Z, dZ>) / Z at V = 0 (reparam.py:262-281); V_i = w V_direct, div_i = <d_w_omega, V_direct>
+__device__ __forceinline__ v3 reparam_grad_vdirect(const hf_reparam_args &a, size_t i, v3 d, float w, v3 dw) {
+    const float Z = fmaxf(a.Z[i], 1e-8f), iZ = 1.0f / Z;
+    const v3 gd = mk3(a.g_dir[0][i], a.g_dir[1][i], a.g_dir[2][i]);
+    const float gdiv = a.g_div[i];
+    const float dd = dot3(d, d), idn = 1.0f / __builtin_sqrtf(dd);
+    const float pr = dot3(d, gd) / dd;
+    const v3 dZ = mk3(a.dZ[0][i], a.dZ[1][i], a.dZ[2][i]);
+    const float c = gdiv * iZ * iZ;
+    const v3 gV = mk3((gd.x - d.x * pr) * idn * iZ - c * dZ.x, (gd.y - d.y * pr) * idn * iZ - c * dZ.y,
+                      (gd.z - d.z * pr) * idn * iZ - c * dZ.z);
+    const float gdivV = gdiv * iZ;
+    return mk3(__builtin_fmaf(w, gV.x, gdivV * dw.x), __builtin_fmaf(w, gV.y, gdivV * dw.y),
+               __builtin_fmaf(w, gV.z, gdivV * dw.z));
+}
+
 struct hf_grad_dev {
     const float *t, *p[3], *n[3], *uv[2], *sh_n[3], *dp_du[3], *dp_dv[3];
 };
 __device__ __forceinline__ float ld(const float *p, size_t i) { return p ? p[i] : 0.f; }
 __device__ __forceinline__ v3 ld3(const float *const p[3], size_t i) { return mk3(ld(p[0], i), ld(p[1], i), ld(p[2], i)); }
 
+// REPARAM: sample ra.k of the second loop of the warped-area reparameterisation (reparam.py:296-325) in one pass --
+// the auxiliary ray is regenerated from the primary ray, (grad_t, grad_p) are mode 1 of hf_reparam_weight_kernel
+// evaluated in registers (rays / g are unused; flags = All | FollowShape | BoundaryTest).
+template <bool REPARAM>
 __global__ __launch_bounds__(HF_BLOCK, 5) void hf_adjoint_kernel(hf_dev_field f, size_t n, hf_rays_dev rays,
                                                               hf_pi_cdev pi, const uint8_t *__restrict__ active,
                                                               hf_grad_dev g, uint32_t flags,
                                                               float *__restrict__ grad_h, float *go0, float *go1,
-                                                              float *go2, float *gd0, float *gd1, float *gd2) {
+                                                              float *go2, float *gd0, float *gd1, float *gd2,
+                                                              hf_reparam_args ra) {
     const bool follow = (flags & 0x80u) != 0, detach = (flags & 0x100u) != 0;
     const bool tex = (flags & (0x2u | 0x4u)) != 0;
     // Wave-level pre-reduction of the scatter: the hits of one wave (one pixel's samples for
@@ -1076,8 +1157,18 @@ __global__ __launch_bounds__(HF_BLOCK, 5) void hf_adjoint_kernel(hf_dev_field f,
         int vr[3] = { 0, 0, 0 }, vc[3] = { 0, 0, 0 };
         bool scatter = false;
         if (act) {
-            const v3 o = mk3(rays.o[0][i], rays.o[1][i], rays.o[2][i]);
-            const v3 d = mk3(rays.d[0][i], rays.d[1][i], rays.d[2][i]);
+            v3 o, d;
+            hf_aux_sample q;
+            v3 d_primary;
+            if (REPARAM) {
+                o = mk3(ra.o[0][i], ra.o[1][i], ra.o[2][i]);
+                d_primary = mk3(ra.d[0][i], ra.d[1][i], ra.d[2][i]);
+                aux_sample(ra, i, d_primary, q);
+                d = frame_to_world(q, d_primary, q.omega); // = hf_reparam_aux_kernel's direction
+            } else {
+                o = mk3(rays.o[0][i], rays.o[1][i], rays.o[2][i]);
+                d = mk3(rays.d[0][i], rays.d[1][i], rays.d[2][i]);
+            }
             const float b1 = pi.u[i], b2 = pi.v[i], b0 = 1.f - b1 - b2;
             const uint32_t prim = pi.prim[i];
             v3 P[3];
@@ -1090,11 +1181,25 @@ __global__ __launch_bounds__(HF_BLOCK, 5) void hf_adjoint_kernel(hf_dev_field f,
                              __builtin_fmaf(P[0].z, b0, __builtin_fmaf(P[1].z, b1, P[2].z * b2)));
             const v3 z3 = mk3(0.f, 0.f, 0.f);
             v3 gP0 = z3, gP1 = z3, gP2 = z3, gdp0 = z3, gdp1 = z3;
-            v3 gp = ld3(g.p, i);
-            const float gt = ld(g.t, i);
+            v3 gp;
+            float gt;
+            if (REPARAM) {
+                float w;
+                v3 dw;
+                reparam_weight(ra, q, d_primary, ra.si_bt[i], w, dw);
+                const v3 gVd = reparam_grad_vdirect(ra, i, d_primary, w, dw);
+                // V_direct = (si.p - o) / si.t with the FollowShape t of compute_si (same expressions: same bits)
+                const v3 po = p - o;
+                const float it = 1.0f / __builtin_sqrtf(dot3(po, po) / dot3(d, d));
+                gp = mk3(gVd.x * it, gVd.y * it, gVd.z * it);
+                gt = -dot3(gVd, po) * it * it;
+            } else {
+                gp = ld3(g.p, i);
+                gt = ld(g.t, i);
+            }
 
             // dp_du / dp_dv from the (constant) texcoord differences
-            if (flags & 0x4u) {
+            if (!REPARAM && (flags & 0x4u)) {
                 const float du0 = U[1] - U[0], dv0 = V[1] - V[0], du1 = U[2] - U[0], dv1 = V[2] - V[0];
                 const float det = __builtin_fmaf(du0, dv1, -(dv0 * du1));
                 const float inv_det = rcp_ieee(det);
@@ -1107,7 +1212,7 @@ __global__ __launch_bounds__(HF_BLOCK, 5) void hf_adjoint_kernel(hf_dev_field f,
                 }
             }
             // n = sh_n = +-normalize(cross(dp0, dp1))
-            {
+            if (!REPARAM) {
                 const v3 N = cross3(dp0, dp1);
                 const float r = rsqrt_ieee(dot3(N, N));
                 const v3 nn = N * r;
@@ -1129,7 +1234,7 @@ __global__ __launch_bounds__(HF_BLOCK, 5) void hf_adjoint_kernel(hf_dev_field f,
                 axpy3(-gt * tt / dd, d, gd);
             }
             // p = sum b_k P_k, uv = sum b_k uv_k
-            const float guv0 = ld(g.uv[0], i), guv1 = ld(g.uv[1], i);
+            const float guv0 = REPARAM ? 0.f : ld(g.uv[0], i), guv1 = REPARAM ? 0.f : ld(g.uv[1], i);
             float gb0 = dot3(gp, P[0]), gb1 = dot3(gp, P[1]), gb2 = dot3(gp, P[2]);
             if (tex) {
                 gb0 += guv0 * U[0] + guv1 * V[0];
@@ -1226,10 +1331,21 @@ void hf_launch_adjoint(const hf_dev_field &f, size_t n, const hf_rays_t *rays, c
         g.dp_du[k] = gs->dp_du[k]; g.dp_dv[k] = gs->dp_dv[k];
     }
     g.uv[0] = gs->uv[0]; g.uv[1] = gs->uv[1];
-    hipLaunchKernelGGL(hf_adjoint_kernel, dim3(grid_for(n)), dim3(HF_BLOCK), 0, stream, f, n, to_dev(rays), p, active,
-                       g, flags, grad_h, grad_o ? grad_o[0] : nullptr, grad_o ? grad_o[1] : nullptr,
+    hipLaunchKernelGGL(hf_adjoint_kernel<false>, dim3(grid_for(n)), dim3(HF_BLOCK), 0, stream, f, n, to_dev(rays), p,
+                       active, g, flags, grad_h, grad_o ? grad_o[0] : nullptr, grad_o ? grad_o[1] : nullptr,
                        grad_o ? grad_o[2] : nullptr, grad_d ? grad_d[0] : nullptr, grad_d ? grad_d[1] : nullptr,
-                       grad_d ? grad_d[2] : nullptr);
+                       grad_d ? grad_d[2] : nullptr, hf_reparam_args{});
+}
+
+void hf_launch_reparam_adjoint(const hf_dev_field &f, const hf_reparam_args &a, const hf_pi_const_t *pi, float *grad_h,
+                               hipStream_t stream) {
+    if (a.n == 0) return;
+    const hf_pi_cdev p = { pi->t, pi->prim_uv[0], pi->prim_uv[1], pi->prim_index };
+    hf_rays_dev nr = {};
+    hf_grad_dev ng = {};
+    const uint32_t flags = 0x1u | 0x2u | 0x4u | 0x8u | 0x10u | 0x20u | 0x40u | 0x80u; // All | BoundaryTest | FollowShape
+    hipLaunchKernelGGL(hf_adjoint_kernel<true>, dim3(grid_for(a.n)), dim3(HF_BLOCK), 0, stream, f, a.n, nr, p, a.active,
+                       ng, flags, grad_h, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, a);
 }
 
 // ---------------------------------------------------------------------------------
@@ -1341,48 +1457,7 @@ void hf_launch_direct_adjoint(size_t n, uint32_t spp, const float *const sh_n[3]
                        lights, grad_image, gn);
 }
 
-// ---------------------------------------------------------------------------------
-// Warped-area reparameterisation (include/hf.h; reparam.py:10-123,224-333): per-sample kernels
-// ---------------------------------------------------------------------------------
-__device__ __forceinline__ void tea32(uint32_t v0, uint32_t v1, uint32_t &o0, uint32_t &o1) { // random.h:76-91
-    uint32_t sum = 0;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        sum += 0x9e3779b9u;
-        v0 += ((v1 << 4) + 0xa341316cu) ^ (v1 + sum) ^ ((v1 >> 5) + 0xc8013ea4u);
-        v1 += ((v0 << 4) + 0xad90777du) ^ (v0 + sum) ^ ((v0 >> 5) + 0x7e95761eu);
-    }
-    o0 = v0; o1 = v1;
-}
-
-struct hf_aux_sample {
-    v3 omega;     // square_to_von_mises_fisher(sample, kappa), xy negated on the flipped half of a pair
-    float sy;     // sample.y
-    v3 fs, ft;    // Frame3f(d): s, t (n = d)
-};
-__device__ __forceinline__ void aux_sample(const hf_reparam_args &a, size_t i, v3 d, hf_aux_sample &q) {
-    const uint32_t pair = a.antithetic ? (a.k >> 1) : a.k;
-    uint32_t r0, r1;
-    tea32(a.seed + pair, (uint32_t) i, r0, r1);
-    const float sx = (float) (r0 >> 9) * (1.0f / 8388608.0f), sy = (float) (r1 >> 9) * (1.0f / 8388608.0f);
-    // warp.h:557-566
-    const float syc = fmaxf(1.f - sy, 1e-6f);
-    const float cos_theta = 1.f + logf(__builtin_fmaf(1.f - syc, expf(-2.f * a.kappa), syc)) / a.kappa;
-    float sn, cs;
-    sincosf(6.283185307179586f * sx, &sn, &cs);
-    const float sin_theta = __builtin_sqrtf(fmaxf(1.f - cos_theta * cos_theta, 0.f));
-    const bool flip = a.antithetic && ((a.k & 1u) == 0u); // reparam.py:83-85,189
-    q.omega = mk3(flip ? -(cs * sin_theta) : cs * sin_theta, flip ? -(sn * sin_theta) : sn * sin_theta, cos_theta);
-    q.sy = sy;
-    coordinate_system(d, q.fs, q.ft);
-}
-// Frame3f::to_world (frame.h:39-41)
-__device__ __forceinline__ v3 frame_to_world(const hf_aux_sample &q, v3 n, v3 v) {
-    return mk3(__builtin_fmaf(n.x, v.z, __builtin_fmaf(q.ft.x, v.y, q.fs.x * v.x)),
-               __builtin_fmaf(n.y, v.z, __builtin_fmaf(q.ft.y, v.y, q.fs.y * v.x)),
-               __builtin_fmaf(n.z, v.z, __builtin_fmaf(q.ft.z, v.y, q.fs.z * v.x)));
-}
-
+// ---- warped-area reparameterisation: per-sample kernels (helpers: above hf_adjoint_kernel) ----
 __global__ __launch_bounds__(HF_BLOCK) void hf_reparam_aux_kernel(hf_reparam_args a) {
     const size_t i = (size_t) blockIdx.x * HF_BLOCK + threadIdx.x;
     if (i >= a.n) return;
@@ -1403,15 +1478,10 @@ __global__ __launch_bounds__(HF_BLOCK) void hf_reparam_weight_kernel(hf_reparam_
     aux_sample(a, i, d, q);
     const float t = a.si_t[i];
     const bool hit = act && (t != __builtin_inff());
-    // reparam.py:103-121
     const float B = hit ? a.si_bt[i] : 1.0f;
-    const float inv_vmf = 1.0f / __builtin_fmaf(q.sy, expf(-2.f * a.kappa), 1.f - q.sy);
-    const float w_denom = inv_vmf - 1.f + B;
-    const float w_rcp = (w_denom > 1e-4f) ? 1.0f / w_denom : 0.f;
-    const float w = powf(w_rcp, a.exponent) * inv_vmf;
-    const float tmp1 = fminf(fmaxf(inv_vmf * w * w_rcp * a.kappa * a.exponent, -1e10f), 1e10f);
-    const v3 tmp2 = frame_to_world(q, d, mk3(q.omega.x, q.omega.y, 0.f));
-    const v3 dw = mk3(tmp1 * tmp2.x, tmp1 * tmp2.y, tmp1 * tmp2.z);
+    float w;
+    v3 dw;
+    reparam_weight(a, q, d, B, w, dw);
     if (a.mode == 0) {
         if (!act) return;
         a.Z[i] += w;
@@ -1421,22 +1491,9 @@ __global__ __launch_bounds__(HF_BLOCK) void hf_reparam_weight_kernel(hf_reparam_
     v3 gp = mk3(0.f, 0.f, 0.f), gvd = mk3(0.f, 0.f, 0.f);
     float gt = 0.f;
     if (act) {
-        // backward of direction = normalize(d + V/Z), divergence = (div - <V/Z, dZ>) / Z at V = 0 (reparam.py:262-281)
-        const float Z = fmaxf(a.Z[i], 1e-8f), iZ = 1.0f / Z;
-        const v3 gd = mk3(a.g_dir[0][i], a.g_dir[1][i], a.g_dir[2][i]);
-        const float gdiv = a.g_div[i];
-        const float dd = dot3(d, d), idn = 1.0f / __builtin_sqrtf(dd);
-        const float pr = dot3(d, gd) / dd;
-        const v3 dZ = mk3(a.dZ[0][i], a.dZ[1][i], a.dZ[2][i]);
-        const float c = gdiv * iZ * iZ;
-        const v3 gV = mk3((gd.x - d.x * pr) * idn * iZ - c * dZ.x, (gd.y - d.y * pr) * idn * iZ - c * dZ.y,
-                          (gd.z - d.z * pr) * idn * iZ - c * dZ.z);
-        const float gdivV = gdiv * iZ;
-        // this sample: V_i = w V_direct, div_i = <d_w_omega, V_direct>, V_direct = (p - o) / t
-        const v3 gVd = mk3(__builtin_fmaf(w, gV.x, gdivV * dw.x), __builtin_fmaf(w, gV.y, gdivV * dw.y),
-                           __builtin_fmaf(w, gV.z, gdivV * dw.z));
+        const v3 gVd = reparam_grad_vdirect(a, i, d, w, dw);
         gvd = gVd;
-        if (hit) {
+        if (hit) { // V_direct = (p - o) / t
             const v3 po = mk3(a.si_p[0][i] - o.x, a.si_p[1][i] - o.y, a.si_p[2][i] - o.z);
             const float it = 1.0f / t;
             gp = mk3(gVd.x * it, gVd.y * it, gVd.z * it);
@@ -1446,6 +1503,39 @@ __global__ __launch_bounds__(HF_BLOCK) void hf_reparam_weight_kernel(hf_reparam_
     a.g_p[0][i] = gp.x; a.g_p[1][i] = gp.y; a.g_p[2][i] = gp.z;
     a.g_t[i] = gt;
     if (a.g_vd[0]) { a.g_vd[0][i] = gvd.x; a.g_vd[1][i] = gvd.y; a.g_vd[2][i] = gvd.z; }
+}
+
+// mode 0 of hf_reparam_weight_kernel for all samples of a ray in one pass (reparam.py:236-256): Z = sum_k w_k,
+// dZ = sum_k d_w_omega_k, summed in sample order from zero (= what the per-sample launches leave in memory).
+// si_t / si_bt of sample k are at [k * stride + i].
+__global__ __launch_bounds__(HF_BLOCK) void hf_reparam_norm_kernel(hf_reparam_args a, uint32_t num_rays, size_t stride) {
+    const size_t i = (size_t) blockIdx.x * HF_BLOCK + threadIdx.x;
+    if (i >= a.n) return;
+    const bool act = !(a.active && a.active[i] == 0);
+    float Z = 0.f;
+    v3 dZ = mk3(0.f, 0.f, 0.f);
+    if (act) {
+        const v3 d = mk3(a.d[0][i], a.d[1][i], a.d[2][i]);
+        for (uint32_t k = 0; k < num_rays; ++k) {
+            a.k = k;
+            hf_aux_sample q;
+            aux_sample(a, i, d, q);
+            const bool hit = a.si_t[k * stride + i] != __builtin_inff();
+            const float B = hit ? a.si_bt[k * stride + i] : 1.0f;
+            float w;
+            v3 dw;
+            reparam_weight(a, q, d, B, w, dw);
+            Z += w;
+            dZ.x += dw.x; dZ.y += dw.y; dZ.z += dw.z;
+        }
+    }
+    a.Z[i] = Z;
+    a.dZ[0][i] = dZ.x; a.dZ[1][i] = dZ.y; a.dZ[2][i] = dZ.z;
+}
+void hf_launch_reparam_norm(const hf_reparam_args &a, uint32_t num_rays, size_t stride, hipStream_t stream) {
+    if (a.n == 0) return;
+    hipLaunchKernelGGL(hf_reparam_norm_kernel, dim3((unsigned) ((a.n + HF_BLOCK - 1) / HF_BLOCK)), dim3(HF_BLOCK), 0, stream,
+                       a, num_rays, stride);
 }
 
 void hf_launch_reparam_aux(const hf_reparam_args &a, hipStream_t stream) {

@@ -675,6 +675,9 @@ def _coordinate_system(n):
     return s, t
 
 
+REPARAM_FUSED = True   # tests switch this off to compare with the per-sample kernels
+
+
 class _ReparameterizeOp(torch.autograd.Function):
     """reparam.py:126-333 for a scene that is one heightfield: identity in primal mode; in backward mode the
     warped-area gradient of (direction, determinant) with respect to the heights AND the ray (reparam.py:296-325
@@ -722,7 +725,11 @@ class _ReparameterizeOp(torch.autograd.Function):
         # The auxiliary hits of the first loop (36 B per ray and sample: pi + si.t, si.p, si.boundary_test) are kept
         # for the second one when they fit; the reference re-traces (reparam.py:296-325), which is the fallback.
         keep = 36 * n * num_rays <= (16 << 30)
-        bufs = [torch.empty((9, n), dtype=torch.float32, device=dev) for _ in range(num_rays if keep else 1)]
+        store = torch.empty((num_rays if keep else 1, 9, n), dtype=torch.float32, device=dev)
+        bufs = [store[k] for k in range(store.shape[0])]
+        # heights only and the hits kept: the two loops run fused (hf_reparam_normalization: mode 0 of all samples in
+        # one pass; hf_reparam_adjoint: auxiliary ray + mode 1 + adjoint of a sample in one kernel)
+        fused = REPARAM_FUSED and keep and not ray_grads
 
         def structs(buf):
             rows = _rows(buf, n)   # si.t, si.p[3], boundary_test | pi.t, u, v, prim_index
@@ -754,8 +761,20 @@ class _ReparameterizeOp(torch.autograd.Function):
 
         for k in range(num_rays):           # weight normalisation (reparam.py:236-256)
             buf = bufs[k if keep else 0]
-            trace(k, buf); weights(0, k, buf)
-        for k in range(num_rays):           # back-propagation of every sample (reparam.py:296-325)
+            trace(k, buf)
+            if not fused:
+                weights(0, k, buf)
+        if fused:
+            base = store.data_ptr()
+            check(L.hf_reparam_normalization(n, C.byref(d_p), act_p, num_rays, kappa, exponent, int(antithetic), seed,
+                                             base, base + 4 * 4 * n, 9 * n, Z.data_ptr(), C.byref(dZ_p), stream))
+            if need_h:
+                for k in range(num_rays):   # back-propagation of every sample (reparam.py:296-325)
+                    rows, si_s, pi_s = structs(bufs[k])
+                    check(L.hf_reparam_adjoint(shape._h, n, C.byref(o_p), C.byref(d_p), act_p, k, kappa, exponent,
+                                               int(antithetic), seed, C.byref(pi_s), rows[4], Z.data_ptr(),
+                                               C.byref(dZ_p), C.byref(gd_p), gdiv.data_ptr(), grad_h.data_ptr(), stream))
+        for k in range(0 if fused else num_rays):   # the same, per-sample kernels (ray gradients wanted / hits not kept)
             buf = bufs[k if keep else 0]
             if keep:
                 aux(k)                      # hf_adjoint needs the auxiliary ray again, not its trace

@@ -81,6 +81,41 @@ def test_gpu_reparameterize_ray_matches_oracle(hf, oracle, kappa, antithetic, nu
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kappa,antithetic,num_rays", [(30.0, False, 5), (2000.0, True, 8), (1e5, False, 4)])
+def test_gpu_fused_loops_equal_the_per_sample_kernels(hf, kappa, antithetic, num_rays):
+    """hf_reparam_normalization + hf_reparam_adjoint (the default when only the heights are differentiated) against
+    hf_reparam_aux_rays / hf_reparam_weights / hf_adjoint per sample: the same arithmetic, so the only difference is
+    the order of the float atomics of the scatter."""
+    import torch
+    from hf_amd import shape as shape_mod
+    rng = np.random.default_rng(11)
+    W, H = 65, 47
+    u = np.arange(W) / (W - 1.0); v = np.arange(H)[:, None] / (H - 1.0)
+    h = (0.5 + 0.3 * np.sin(2 * np.pi * 1.5 * u) * np.cos(2 * np.pi * 1.2 * v) + 0.03 * rng.uniform(-1, 1, (H, W))).astype(np.float32)
+    n = 20000
+    o, d = _rays(n, rng)
+    active = torch.from_numpy(rng.uniform(size=n) < 0.9).cuda()
+    gd = torch.from_numpy(rng.normal(size=(3, n)).astype(np.float32)).cuda()
+    gdiv = torch.from_numpy(rng.normal(size=n).astype(np.float32)).cuda()
+    grads = []
+    for fused in (True, False):
+        shape_mod.REPARAM_FUSED = fused
+        try:
+            shape = hf.Heightfield(heightfield=torch.from_numpy(h).cuda(), max_height=0.5)
+            shape.heightfield.requires_grad_(True)
+            ray = hf.Ray3f(torch.from_numpy(o).cuda(), torch.from_numpy(d).cuda())
+            dirn, det = hf.reparameterize_ray(shape, ray, num_rays=num_rays, kappa=kappa, exponent=3.0,
+                                              antithetic=antithetic, seed=7, active=active)
+            ((dirn * gd).sum() + (det * gdiv).sum()).backward()
+            grads.append(shape.heightfield.grad.double().cpu().numpy())
+        finally:
+            shape_mod.REPARAM_FUSED = True
+    assert np.linalg.norm(grads[1]) > 0
+    rel = np.linalg.norm(grads[0] - grads[1]) / np.linalg.norm(grads[1])
+    assert rel <= 2e-6, rel
+
+
+@pytest.mark.gpu
 def test_gpu_aux_rays_match_oracle(hf, oracle):
     import ctypes as C
     import torch
