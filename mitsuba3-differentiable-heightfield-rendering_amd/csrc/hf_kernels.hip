@@ -1076,7 +1076,7 @@ __device__ __forceinline__ void aux_sample(const hf_reparam_args &a, size_t i, v
     const float syc = fmaxf(1.f - sy, 1e-6f);
     const float cos_theta = 1.f + logf(__builtin_fmaf(1.f - syc, expf(-2.f * a.kappa), syc)) / a.kappa;
     float sn, cs;
-    sincosf(6.283185307179586f * sx, &sn, &cs);
+    sincospif(2.f * sx, &sn, &cs); // sin / cos of 2 pi sx without the range reduction of a radian argument
     const float sin_theta = __builtin_sqrtf(fmaxf(1.f - cos_theta * cos_theta, 0.f));
     const bool flip = a.antithetic && ((a.k & 1u) == 0u); // reparam.py:83-85,189
     q.omega = mk3(flip ? -(cs * sin_theta) : cs * sin_theta, flip ? -(sn * sin_theta) : sn * sin_theta, cos_theta);
@@ -1096,7 +1096,8 @@ __device__ __forceinline__ void reparam_weight(const hf_reparam_args &a, const h
     const float inv_vmf = 1.0f / __builtin_fmaf(q.sy, expf(-2.f * a.kappa), 1.f - q.sy);
     const float w_denom = inv_vmf - 1.f + B;
     const float w_rcp = (w_denom > 1e-4f) ? 1.0f / w_denom : 0.f;
-    w = powf(w_rcp, a.exponent) * inv_vmf;
+    // (the exponent of the reference's callers is 3: three multiplications instead of exp2(y log2 x))
+    w = (a.exponent == 3.f ? (w_rcp * w_rcp) * w_rcp : powf(w_rcp, a.exponent)) * inv_vmf;
     const float tmp1 = fminf(fmaxf(inv_vmf * w * w_rcp * a.kappa * a.exponent, -1e10f), 1e10f);
     const v3 tmp2 = frame_to_world(q, d, mk3(q.omega.x, q.omega.y, 0.f));
     dw = mk3(tmp1 * tmp2.x, tmp1 * tmp2.y, tmp1 * tmp2.z);
