@@ -257,59 +257,90 @@ __device__ __forceinline__ void prim_world(const hf_dev_field &f, uint32_t prim,
     }
 }
 
-// Shape::compute_surface_interaction + finalize_surface_interaction for one valid hit
-__device__ __forceinline__ void compute_si(const hf_dev_field &f, v3 o, v3 d, float t_in, float b1, float b2,
-                                           uint32_t prim, uint32_t flags, hf_si_rec &si) {
+// Shape::compute_surface_interaction + finalize_surface_interaction for one valid hit.
+// The fields are handed to `out` as soon as they are final (out.t(..), out.p(..), ...): the record sink below collects
+// them into an hf_si_rec; the fused traversal kernel stores each one straight away, so that the whole record is
+// never live in registers at once.
+template <typename Out>
+__device__ __forceinline__ void compute_si_to(const hf_dev_field &f, v3 o, v3 d, float t_in, float b1, float b2,
+                                              uint32_t prim, uint32_t flags, Out &out) {
     v3 P[3];
     float U[3], V[3];
     int vi[3], vj[3];
     prim_world(f, prim, P, U, V, vi, vj);
     const float b0 = 1.f - b1 - b2;
     const v3 dp0 = P[1] - P[0], dp1 = P[2] - P[0];
-    si.p = mk3(__builtin_fmaf(P[0].x, b0, __builtin_fmaf(P[1].x, b1, P[2].x * b2)),
-               __builtin_fmaf(P[0].y, b0, __builtin_fmaf(P[1].y, b1, P[2].y * b2)),
-               __builtin_fmaf(P[0].z, b0, __builtin_fmaf(P[1].z, b1, P[2].z * b2)));
+    const v3 p = mk3(__builtin_fmaf(P[0].x, b0, __builtin_fmaf(P[1].x, b1, P[2].x * b2)),
+                     __builtin_fmaf(P[0].y, b0, __builtin_fmaf(P[1].y, b1, P[2].y * b2)),
+                     __builtin_fmaf(P[0].z, b0, __builtin_fmaf(P[1].z, b1, P[2].z * b2)));
     float t = t_in;
     if (flags & 0x80u) { // FollowShape: t re-derived from the glued point (mesh.cpp:748-752)
-        const v3 po = si.p - o;
+        const v3 po = p - o;
         t = __builtin_sqrtf(dot3(po, po) / dot3(d, d));
     }
-    si.t = t;
-    si.n = normalize3(cross3(dp0, dp1));
-    si.uv0 = b1; si.uv1 = b2;
-    coordinate_system(si.n, si.dp_du, si.dp_dv);
+    out.t(t);
+    out.p(p);
+    if (flags & 0x40u)
+        out.boundary_test(boundary_test_flat(p, P[0], dp0, dp1, silhouette_edges(f, prim, xform_vec(f.to_object, d))));
+    else
+        out.boundary_test(0.f);
+    v3 n = normalize3(cross3(dp0, dp1));
+    float uv0 = b1, uv1 = b2;
+    v3 dp_du, dp_dv;
+    coordinate_system(n, dp_du, dp_dv);
     if (flags & (0x2u | 0x4u)) {
-        si.uv0 = __builtin_fmaf(U[2], b2, __builtin_fmaf(U[1], b1, U[0] * b0));
-        si.uv1 = __builtin_fmaf(V[2], b2, __builtin_fmaf(V[1], b1, V[0] * b0));
+        uv0 = __builtin_fmaf(U[2], b2, __builtin_fmaf(U[1], b1, U[0] * b0));
+        uv1 = __builtin_fmaf(V[2], b2, __builtin_fmaf(V[1], b1, V[0] * b0));
         if (flags & 0x4u) {
             const float du0 = U[1] - U[0], dv0 = V[1] - V[0], du1 = U[2] - U[0], dv1 = V[2] - V[0];
             const float det = __builtin_fmaf(du0, dv1, -(dv0 * du1));
             const float inv_det = rcp_ieee(det);
             if (det != 0.f) {
-                si.dp_du = mk3(__builtin_fmaf(dv1, dp0.x, -(dv0 * dp1.x)) * inv_det,
-                               __builtin_fmaf(dv1, dp0.y, -(dv0 * dp1.y)) * inv_det,
-                               __builtin_fmaf(dv1, dp0.z, -(dv0 * dp1.z)) * inv_det);
-                si.dp_dv = mk3(__builtin_fmaf(-du1, dp0.x, du0 * dp1.x) * inv_det,
-                               __builtin_fmaf(-du1, dp0.y, du0 * dp1.y) * inv_det,
-                               __builtin_fmaf(-du1, dp0.z, du0 * dp1.z) * inv_det);
+                dp_du = mk3(__builtin_fmaf(dv1, dp0.x, -(dv0 * dp1.x)) * inv_det,
+                            __builtin_fmaf(dv1, dp0.y, -(dv0 * dp1.y)) * inv_det,
+                            __builtin_fmaf(dv1, dp0.z, -(dv0 * dp1.z)) * inv_det);
+                dp_dv = mk3(__builtin_fmaf(-du1, dp0.x, du0 * dp1.x) * inv_det,
+                            __builtin_fmaf(-du1, dp0.y, du0 * dp1.y) * inv_det,
+                            __builtin_fmaf(-du1, dp0.z, du0 * dp1.z) * inv_det);
             }
         }
     }
-    si.sh_n = si.n;
-    if (f.flip) { si.n = neg3(si.n); si.sh_n = neg3(si.sh_n); }
-    si.boundary_test = 0.f;
-    if (flags & 0x40u)
-        si.boundary_test = boundary_test_flat(si.p, P[0], dp0, dp1, silhouette_edges(f, prim, xform_vec(f.to_object, d)));
-    si.sh_s = mk3(0.f, 0.f, 0.f); si.sh_t = mk3(0.f, 0.f, 0.f);
+    out.uv(uv0, uv1);
+    out.dp_dv(dp_dv);
+    if (f.flip) n = neg3(n);
+    out.n(n); // n and sh_n
+    v3 sh_s = mk3(0.f, 0.f, 0.f), sh_t = mk3(0.f, 0.f, 0.f);
     if (flags & 0x8u) { // initialize_sh_frame: Gram-Schmidt on dp_du
-        const float nd = -dot3(si.sh_n, si.dp_du);
-        si.sh_s = normalize3(fma3(si.sh_n, nd, si.dp_du));
-        if (si.dp_du.x == 0.f && si.dp_du.y == 0.f && si.dp_du.z == 0.f) {
+        const float nd = -dot3(n, dp_du);
+        sh_s = normalize3(fma3(n, nd, dp_du));
+        if (dp_du.x == 0.f && dp_du.y == 0.f && dp_du.z == 0.f) {
             v3 dummy;
-            coordinate_system(si.sh_n, si.sh_s, dummy);
+            coordinate_system(n, sh_s, dummy);
         }
-        si.sh_t = cross3(si.sh_n, si.sh_s);
+        sh_t = cross3(n, sh_s);
     }
+    out.dp_du(dp_du);
+    out.sh_s(sh_s);
+    out.sh_t(sh_t);
     const v3 md = neg3(d);
-    si.wi = mk3(dot3(md, si.sh_s), dot3(md, si.sh_t), dot3(md, si.sh_n));
+    out.wi(mk3(dot3(md, sh_s), dot3(md, sh_t), dot3(md, n)));
+}
+
+struct hf_si_rec_sink {
+    hf_si_rec &si;
+    __device__ __forceinline__ void t(float v) { si.t = v; }
+    __device__ __forceinline__ void p(v3 v) { si.p = v; }
+    __device__ __forceinline__ void boundary_test(float v) { si.boundary_test = v; }
+    __device__ __forceinline__ void uv(float a, float b) { si.uv0 = a; si.uv1 = b; }
+    __device__ __forceinline__ void dp_du(v3 v) { si.dp_du = v; }
+    __device__ __forceinline__ void dp_dv(v3 v) { si.dp_dv = v; }
+    __device__ __forceinline__ void n(v3 v) { si.n = v; si.sh_n = v; }
+    __device__ __forceinline__ void sh_s(v3 v) { si.sh_s = v; }
+    __device__ __forceinline__ void sh_t(v3 v) { si.sh_t = v; }
+    __device__ __forceinline__ void wi(v3 v) { si.wi = v; }
+};
+__device__ __forceinline__ void compute_si(const hf_dev_field &f, v3 o, v3 d, float t_in, float b1, float b2,
+                                           uint32_t prim, uint32_t flags, hf_si_rec &si) {
+    hf_si_rec_sink sink = { si };
+    compute_si_to(f, o, d, t_in, b1, b2, prim, flags, sink);
 }

@@ -774,6 +774,29 @@ __device__ __forceinline__ hf_si_dev load_si(hf_kargs_ptr ka) {
     return d;
 }
 
+// compute_si_to sink of the fused mode: a field goes to memory when it is final; the row pointers are read from the
+// kernarg segment at the store
+struct hf_si_store_sink {
+    hf_kargs_ptr ka;
+    size_t ub;
+    uint32_t lo, flags;
+    __device__ __forceinline__ void s1(float *p, float v) { st(p, ub, lo, v); }
+    __device__ __forceinline__ void s3(float *p0, float *p1, float *p2, v3 v) { st(p0, ub, lo, v.x); st(p1, ub, lo, v.y); st(p2, ub, lo, v.z); }
+    __device__ __forceinline__ void t(float v) { s1(ka->sio.t, v); }
+    __device__ __forceinline__ void p(v3 v) { s3(ka->sio.p[0], ka->sio.p[1], ka->sio.p[2], v); }
+    __device__ __forceinline__ void boundary_test(float v) { if (flags & 0x40u) s1(ka->sio.bt, v); }
+    __device__ __forceinline__ void uv(float a, float b) { s1(ka->sio.uv[0], a); s1(ka->sio.uv[1], b); }
+    __device__ __forceinline__ void dp_du(v3 v) { s3(ka->sio.dp_du[0], ka->sio.dp_du[1], ka->sio.dp_du[2], v); }
+    __device__ __forceinline__ void dp_dv(v3 v) { s3(ka->sio.dp_dv[0], ka->sio.dp_dv[1], ka->sio.dp_dv[2], v); }
+    __device__ __forceinline__ void n(v3 v) {
+        s3(ka->sio.n[0], ka->sio.n[1], ka->sio.n[2], v);
+        s3(ka->sio.sh_n[0], ka->sio.sh_n[1], ka->sio.sh_n[2], v);
+    }
+    __device__ __forceinline__ void sh_s(v3 v) { s3(ka->sio.sh_s[0], ka->sio.sh_s[1], ka->sio.sh_s[2], v); }
+    __device__ __forceinline__ void sh_t(v3 v) { s3(ka->sio.sh_t[0], ka->sio.sh_t[1], ka->sio.sh_t[2], v); }
+    __device__ __forceinline__ void wi(v3 v) { s3(ka->sio.wi[0], ka->sio.wi[1], ka->sio.wi[2], v); }
+};
+
 // Persistent waves: every wave pulls `grab` consecutive rays at a time from a global
 // counter (zeroed on the stream before the launch), so expensive image regions are
 // spread over all CUs whatever their position in the wavefront.
@@ -912,18 +935,21 @@ __global__ __launch_bounds__(HF_BLOCK, (MODE == 2 ? HF_TRACE_WAVES_FUSED : HF_TR
                 if (pi.v) (pi.v + ub)[lo] = best.hit ? best.v : 0.f;
                 if (pi.prim) (pi.prim + ub)[lo] = best.hit ? best.prim : 0u;
                 if (MODE == 2) {
-                    hf_si_rec si;
                     const uint32_t flags = ka->flags;
+                    hf_si_store_sink out = { ka, ub, lo, flags };
                     if (best.hit) {
                         // the origin is only needed by a hit: read again (an L2 hit) rather than held across the walk
                         const hf_rays_dev rp = load_rays(ka);
                         const v3 ow = mk3((rp.o[0] + ub)[lo], (rp.o[1] + ub)[lo], (rp.o[2] + ub)[lo]);
                         const hf_dev_field fl = load_field(&ka->f); // to_world etc.: not held across the walk
-                        compute_si(fl, ow, dw, best.t, best.u, best.v, best.prim, flags, si);
+                        // every field is stored as soon as it is final: the record is never whole in registers
+                        compute_si_to(fl, ow, dw, best.t, best.u, best.v, best.prim, flags, out);
+                    } else { // zero-initialised record (interaction.h:479-499, 667-673)
+                        const v3 z = mk3(0.f, 0.f, 0.f);
+                        out.t(__builtin_inff()); out.p(z); out.boundary_test((flags & 0x40u) ? 1e8f : 0.f);
+                        out.uv(0.f, 0.f); out.dp_dv(z); out.n(z); out.dp_du(z); out.sh_s(z); out.sh_t(z);
+                        out.wi(neg3(dw));
                     }
-                    else          miss_si(si, dw, flags);
-                    const hf_si_dev sio = load_si(ka); // all row pointers at once (wide scalar loads), then the stores
-                    store_si(sio, ub, lo, si, flags);
                 }
             }
         }
