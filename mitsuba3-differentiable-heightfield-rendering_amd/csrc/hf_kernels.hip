@@ -604,6 +604,12 @@ __device__ __forceinline__ void walk_rows(const hf_dev_field &f, const hf_ray_st
     hf_src_global src;
     src.mip = f.mip; src.shear = f.shear; src.h = f.h; src.top = f.top; src.W = f.W;
     const uint32_t lfxm = rs.fx ? ((1u << top) - 1u) : 0u, lfym = rs.fy ? ((1u << top) - 1u) : 0u;
+#ifdef HF_TSTATS
+    long long tsub = 0;
+#endif
+#ifdef HF_WSTATS
+    if ((threadIdx.x & 63u) < 8u) wcnt_base()[threadIdx.x & 63u] = 0u;
+#endif
     // rows the wave's rays can touch: [gy - m, gy + m + t_hi dy] per lane, widened by the slack of this estimate
     uint32_t jmin, jmax;
     {
@@ -625,6 +631,7 @@ __device__ __forceinline__ void walk_rows(const hf_dev_field &f, const hf_ray_st
             if (__ballot(ty1 <= thi) == 0ull) break;
             continue;
         }
+        WCOUNT(0);
         uint32_t imin, imax;
         {
             const float dxo = __builtin_fabsf(rs.od.x) * (0.5f * (float) (f.W - 1));
@@ -646,13 +653,22 @@ __device__ __forceinline__ void walk_rows(const hf_dev_field &f, const hf_ray_st
             const bool mine = (u0 <= u1) & (fminf(za, zb) - r.mz <= box.y) & (fmaxf(za, zb) + r.mz >= box.x);
             if (__ballot(mine) == 0ull) continue;
             WCOUNT(2);
+#ifdef HF_TSTATS
+            const long long ts0 = clock64();
+#endif
             if (mine) {
                 const bool h = walk_subtree<ANY>(f, src, rs, r, rs.fx, rs.fy, lfxm, lfym, i, j, HF_SUBTREE_LEVEL, thi, best);
                 if (ANY && h) thi = -1.f;
             }
+#ifdef HF_TSTATS
+            tsub += clock64() - ts0;
+#endif
         }
         if (ANY && __ballot(thi >= 0.f) == 0ull) break;
     }
+#ifdef HF_TSTATS // diagnostic build (scripts/tstats.py): cycles spent in the per-lane walks of this batch
+    if (alive) { best.hit = true; best.u = (float) tsub; }
+#endif
 #ifdef HF_WSTATS
     if (alive) { const uint32_t *c = wcnt_base(); best.hit = true; best.t = (float) c[0] + 1024.f * (float) c[1] + 1048576.f * (float) c[2];
         best.u = (float) c[3] + 4096.f * (float) c[4]; best.v = (float) c[5] + 4096.f * (float) c[6]; }

@@ -19,5 +19,5 @@ w = trav.any(1)
 u, v, t = u[w], v[w], t[w]
 def m(x): return float(x.mean())
 print(f"batches {int(w.sum())}")
-print(f"packet: expansions {m(t % 1024):.1f}, select iterations {m(torch.floor(t / 1024) % 1024):.1f}, hand-offs with work {m(torch.floor(t / 1048576)):.1f}")
+print(f"row sweep: rows with a lane inside {m(t % 1024):.1f}, nodes box-tested {m(torch.floor(t / 1024) % 1024):.1f}, hand-offs with work {m(torch.floor(t / 1048576)):.1f}")
 print(f"subtree (max over lanes of per-call sums; lanes run the same wave-level loop): iterations {m(u % 4096):.1f}, block executions {m(torch.floor(u / 4096)):.1f}, expansions {m(v % 4096):.1f}, cell rounds {m(torch.floor(v / 4096)):.1f}")
