@@ -18,11 +18,10 @@
 // the children the *fat* ray segment [0,t_hi] overlaps; the children of a level-1 node are
 // cells, whose two triangles are then tested.  Pending children live in 4-bit-per-level mask
 // stacks held in registers.
-// The 64 rays of a coherent wave (primary rays: one pixel's samples) share the walk of
-// the upper levels -- node coordinates, masks and stack are wave-uniform and pinned to
-// SGPRs (readfirstlane), a child is entered when __ballot says any lane overlaps it -- and nodes of
-// level HF_SUBTREE_LEVEL are handed to the per-lane walk; an incoherent wave hands the
-// root to every lane.  The per-lane walk runs in converged rounds: lanes walk until they hold
+// The 64 rays of a coherent wave (primary rays: one pixel's samples) share the upper levels:
+// the nodes of level HF_SUBTREE_LEVEL their fat rays can touch are enumerated row by row, front to
+// back, from wave-wide extents (walk_rows), box-tested per lane and handed to the per-lane walk of
+// the lanes that overlap them; an incoherent wave hands the root to every lane.  The per-lane walk runs in converged rounds: lanes walk until they hold
 // candidate cells, and the two-triangle test runs for all of them together, one cell per lane per
 // round.  The visited set is a conservative superset of the cells the ray can hit; the
 // per-triangle test and the tie rule are order independent, so the result equals the brute force's.
