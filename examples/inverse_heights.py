@@ -9,7 +9,10 @@ A minimal direct-lighting differentiable render on top of the heightfield shape:
     loss.backward()  ->  HIP adjoint scatters dL/dheight;  hf_amd.Adam.step() = hf_adam_step: Adam update on the
         device + rebuild of the acceleration data (what params.update / scene.parameters_changed do once per
         optimiser step, util.py:185-232, scene.cpp:343-385)
-Geometry is attached (prb-style); the silhouette term of hf_amd.reparameterize_ray is not part of this loss.
+Geometry is attached (prb-style).  --silhouette adds the discontinuity term the way prb_reparam.py:317-366 does for
+the camera ray: the primary rays go through hf_amd.reparameterize_ray (identity in primal mode), the intersection is
+differentiated w.r.t. the reparameterised direction as well, and every sample is weighted by the determinant; the
+shading of that variant is written in torch (per-sample weights are not part of hf_direct_lighting).
 
     python examples/inverse_heights.py [--grid 128 --film 256 --steps 100]
 With torch.distributed initialised (torchrun), every rank renders its own spp seed and the gradient
@@ -29,7 +32,25 @@ import hf_amd  # noqa: E402
 LIGHTS = torch.tensor([[0.5, 0.2, 0.84], [-0.5, 0.3, 0.81], [0.1, -0.6, 0.79], [0.0, 0.0, 1.0]])
 
 
-def render(shape, ray, lights, spp, shadows=False):
+def render_reparameterized(shape, ray, lights, spp, aux=8, kappa=2e4, seed=0):
+    """primary rays through reparameterize_ray; per-sample diffuse shading x determinant, box film -- all in torch on
+    top of the differentiable si rows (the gradient reaches the heights through hf_adjoint and the auxiliary rays)"""
+    d, det = hf_amd.reparameterize_ray(shape, ray, num_rays=aux, kappa=kappa, exponent=3.0, seed=seed)
+    ray2 = hf_amd.Ray3f(ray.o, d, ray.maxt)
+    si = shape.ray_intersect(ray2, hf_amd.RayFlags.All)
+    valid = si.is_valid()
+    lights = lights.to(si.sh_frame.n.device)
+    facing = valid & (-(si.sh_frame.n * d).sum(0) > 0)
+    cos = torch.clamp((lights[:, :3, None] * si.sh_frame.n[None]).sum(1), min=0.0)            # [K, rays]
+    sample = torch.where(facing[None], cos * (lights[:, 3:4] / math.pi), torch.zeros_like(cos)) * det[None]
+    images = sample.reshape(len(lights), -1, spp).mean(2)
+    depth = torch.where(valid, si.t, torch.zeros_like(si.t))
+    return images, depth, valid
+
+
+def render(shape, ray, lights, spp, shadows=False, silhouette=False, aux=8, kappa=2e4):
+    if silhouette:
+        return render_reparameterized(shape, ray, lights, spp, aux, kappa)
     si = shape.ray_intersect(ray, hf_amd.RayFlags.All)
     valid = si.is_valid()
     vis = None
@@ -50,7 +71,7 @@ def centred_error(h, target):
 
 
 def run(grid=128, film=256, spp=1, steps=100, lr=0.02, device="cuda", verbose=True, seed=0, shadows=False,
-        depth_weight=0.0):
+        depth_weight=0.0, silhouette=False, aux=8, kappa=2e4):
     dev = torch.device(device)
     lights = torch.cat([LIGHTS / LIGHTS.norm(dim=1, keepdim=True), torch.full((len(LIGHTS), 1), math.pi)], 1)  # E = pi
     target_h = hf_amd.workload.sine_heights(grid, grid, device=dev)
@@ -68,7 +89,7 @@ def run(grid=128, film=256, spp=1, steps=100, lr=0.02, device="cuda", verbose=Tr
     t0 = time.perf_counter()
     for it in range(steps):
         opt.zero_grad()
-        images, depth, valid = render(shape, ray, lights, spp, shadows)
+        images, depth, valid = render(shape, ray, lights, spp, shadows, silhouette, aux, kappa)
         both = valid & tgt_valid
         loss = ((images - tgt_img) ** 2).sum(0).mean()          # the multi-light renders only (configs[4])
         if depth_weight > 0:                                    # optional extra supervision, off by default
@@ -104,5 +125,8 @@ if __name__ == "__main__":
     ap.add_argument("--lr", type=float, default=0.02)
     ap.add_argument("--shadows", action="store_true", help="shadow rays towards every light (one ray_test per light)")
     ap.add_argument("--depth-weight", type=float, default=0.0, help="weight of an extra depth term (0 = images only)")
+    ap.add_argument("--silhouette", action="store_true", help="reparameterised primary rays (discontinuity term)")
+    ap.add_argument("--aux", type=int, default=8, help="auxiliary rays per primary ray of --silhouette")
     a = ap.parse_args()
-    run(a.grid, a.film, a.spp, a.steps, a.lr, shadows=a.shadows, depth_weight=a.depth_weight)
+    run(a.grid, a.film, a.spp, a.steps, a.lr, shadows=a.shadows, depth_weight=a.depth_weight, silhouette=a.silhouette,
+        aux=a.aux)

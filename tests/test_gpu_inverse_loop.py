@@ -58,6 +58,26 @@ def test_inverse_loop_with_shadows_runs(hf):
     assert hist[-1] < hist[0]
 
 
+def test_inverse_loop_with_silhouette_term(hf):
+    """--silhouette: reparameterised primary rays in the loop (prb_reparam.py:317-366 for the camera ray).  Its primal
+    images equal the plain render's (the reparameterisation is the identity in primal mode), and the loop descends."""
+    import torch
+    import inverse_heights
+    h = hf.workload.sine_heights(64, 64, device="cuda")
+    shape = hf.Heightfield(heightfield=h, max_height=0.5)
+    rays = hf.workload.ortho_rays(32, 32, 4, "cuda", origin=(0.6, 0.35, 2.0), target=(0.0, 0.0, 0.25), scale=(0.95, 0.95, 1.0))
+    ray = hf.Ray3f(rays[0:3], rays[3:6], rays[6])
+    import math
+    L = inverse_heights.LIGHTS
+    lights = torch.cat([L / L.norm(dim=1, keepdim=True), torch.full((len(L), 1), math.pi)], 1).cuda()
+    with torch.no_grad():
+        a = inverse_heights.render(shape, ray, lights, 4)[0]
+        b = inverse_heights.render(shape, ray, lights, 4, silhouette=True)[0]
+    assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
+    hist, err, wall = inverse_heights.run(grid=64, film=64, spp=4, steps=15, lr=0.02, verbose=False, silhouette=True, aux=4)
+    assert hist[-1] < 0.6 * hist[0], (hist[0], hist[-1])
+
+
 def test_cxx_host_drives_the_abi_without_python(hf):
     """examples/host_loop.cpp: trace -> shade -> adjoints -> Adam through include/hf.h from plain C++
     (built by __graft_entry__.build()); exit code 0 = the loss dropped 5x."""
