@@ -578,7 +578,10 @@ extern "C" int hf_reparam_adjoint(const hf_field_t *hf, size_t n, const float *c
     for (int c = 0; c < 3; ++c) {
         a.o[c] = o[c]; a.d[c] = d[c]; a.dZ[c] = const_cast<float *>(dZ[c]); a.g_dir[c] = grad_direction[c];
     }
-    hf_device_guard guard(hf->device);
+    int cur = -1; // like the other query functions: the launch goes to the caller's current device
+    if (hipGetDevice(&cur) != hipSuccess || cur != hf->device)
+        return fail(HF_EDEVICE, "hf_reparam_adjoint: current HIP device is %d, the heightfield lives on device %d", cur,
+                    hf->device);
     hf_launch_reparam_adjoint(hf->dev, a, pi, grad_heights, (hipStream_t) stream);
     HF_HIP(hipGetLastError());
     return HF_OK;
