@@ -287,28 +287,20 @@ int hf_reparam_weights(int mode, size_t n, const float *const o[3], const float 
                        float *Z, float *const dZ[3], const float *const grad_direction[3],
                        const float *grad_divergence, float *const grad_p[3], float *grad_t,
                        float *const grad_vd[3], hf_stream_t stream);
-/* The two loops again, fused for the case that only the heights are differentiated (grad(ray) not wanted):
- *
- * hf_reparam_normalization = mode 0 of hf_reparam_weights for all num_rays samples of a ray in one pass
- * (reparam.py:236-256): the hits of sample k are at si_t[k * sample_stride + i], si_boundary_test[k * sample_stride + i];
- * Z[n] and dZ[3][n] are OVERWRITTEN with the sums over the samples (summed in sample order from zero, i.e. the very
- * values num_rays mode-0 calls leave behind).
- *
- * hf_reparam_adjoint = sample k of the second loop (reparam.py:296-325) in one kernel: regenerates the auxiliary ray
- * of hf_reparam_aux_rays from (o, d, k, seed), evaluates mode 1 of hf_reparam_weights in registers and runs hf_adjoint
- * (HF_RAY_ALL | HF_RAY_FOLLOWSHAPE | HF_RAY_BOUNDARYTEST) with the resulting (grad_t, grad_p) on the auxiliary hit
- * `pi` (what hf_ray_intersect returned for that auxiliary ray): grad_heights[H*W] is accumulated into (+=).
- * si.t and si.p of the hit are re-derived from pi (same expressions as compute_surface_interaction), so only
- * si_boundary_test[n] is read from the record. */
-int hf_reparam_normalization(size_t n, const float *const d[3], const uint8_t *active, uint32_t num_rays, float kappa,
-                             float exponent, int antithetic, uint32_t seed, const float *si_t,
-                             const float *si_boundary_test, size_t sample_stride, float *Z, float *const dZ[3],
-                             hf_stream_t stream);
-int hf_reparam_adjoint(const hf_field_t *hf, size_t n, const float *const o[3], const float *const d[3],
-                       const uint8_t *active, uint32_t k, float kappa, float exponent, int antithetic, uint32_t seed,
-                       const hf_pi_const_t *pi, const float *si_boundary_test, const float *Z,
-                       const float *const dZ[3], const float *const grad_direction[3], const float *grad_divergence,
-                       float *grad_heights, hf_stream_t stream);
+/* The same backward pass in ONE kernel for the case that only the heights are differentiated (grad(ray) not wanted):
+ * for every ray the weights of its num_rays samples and their sums Z, dZ (reparam.py:236-256), then for every
+ * auxiliary HIT the gradient of its V_direct through the FollowShape surface interaction into grad_heights[H*W]
+ * (accumulated, +=; reparam.py:296-325).  Inputs are the auxiliary hits only -- what hf_ray_intersect returned for
+ * the rays of hf_reparam_aux_rays with HF_RAY_ALL | HF_RAY_FOLLOWSHAPE | HF_RAY_BOUNDARYTEST: sample k of ray i at
+ * index [k * sample_stride + i] of pi->t / prim_uv / prim_index and of si_boundary_test.  The auxiliary directions are
+ * regenerated from (d, k, seed); si.p and si.t are re-derived from pi with compute_surface_interaction's expressions,
+ * so the result equals num_rays x (hf_reparam_weights mode 0), then num_rays x (mode 1 + hf_adjoint) up to the order
+ * of the float atomics.  1 <= num_rays <= 32. */
+int hf_reparam_backward(const hf_field_t *hf, size_t n, const float *const o[3], const float *const d[3],
+                        const uint8_t *active, uint32_t num_rays, float kappa, float exponent, int antithetic,
+                        uint32_t seed, const hf_pi_const_t *pi, const float *si_boundary_test, size_t sample_stride,
+                        const float *const grad_direction[3], const float *grad_divergence, float *grad_heights,
+                        hf_stream_t stream);
 
 /* ---- scalar / packet entry -----------------------------------------------------
  * Shape::ray_intersect_preliminary_scalar / _packet and ray_test_scalar / _packet

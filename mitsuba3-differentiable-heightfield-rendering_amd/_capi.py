@@ -76,11 +76,9 @@ SYMBOLS = {
                                      C.c_float, C.c_float, C.c_int, C.c_uint32, _fp, C.POINTER(_fp * 3), _fp, _fp,
                                      C.POINTER(_fp * 3), C.POINTER(_fp * 3), _fp, C.POINTER(_fp * 3), _fp,
                                      C.POINTER(_fp * 3), C.c_void_p]),
-    "hf_reparam_normalization": (C.c_int, [C.c_size_t, C.POINTER(_fp * 3), _fp, C.c_uint32, C.c_float, C.c_float, C.c_int,
-                                           C.c_uint32, _fp, _fp, C.c_size_t, _fp, C.POINTER(_fp * 3), C.c_void_p]),
-    "hf_reparam_adjoint": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(_fp * 3), C.POINTER(_fp * 3), _fp, C.c_uint32,
-                                     C.c_float, C.c_float, C.c_int, C.c_uint32, C.c_void_p, _fp, _fp, C.POINTER(_fp * 3),
-                                     C.POINTER(_fp * 3), _fp, _fp, C.c_void_p]),
+    "hf_reparam_backward": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(_fp * 3), C.POINTER(_fp * 3), _fp, C.c_uint32,
+                                      C.c_float, C.c_float, C.c_int, C.c_uint32, C.c_void_p, _fp, C.c_size_t,
+                                      C.POINTER(_fp * 3), _fp, _fp, C.c_void_p]),
     "hf_ray_intersect_preliminary_packet": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(_fp * 3), C.POINTER(_fp * 3),
                                                       C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(_fp * 2), C.c_void_p]),
     "hf_ray_test_packet": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(_fp * 3), C.POINTER(_fp * 3), C.c_void_p,

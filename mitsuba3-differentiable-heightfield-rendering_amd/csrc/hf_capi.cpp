@@ -539,50 +539,30 @@ extern "C" int hf_reparam_weights(int mode, size_t n, const float *const o[3], c
     return HF_OK;
 }
 
-extern "C" int hf_reparam_normalization(size_t n, const float *const d[3], const uint8_t *active, uint32_t num_rays,
-                                        float kappa, float exponent, int antithetic, uint32_t seed, const float *si_t,
-                                        const float *si_boundary_test, size_t sample_stride, float *Z,
-                                        float *const dZ[3], hf_stream_t stream) {
-    if (!all3(d) || !si_t || !si_boundary_test || !Z || !dZ || !dZ[0] || !dZ[1] || !dZ[2])
-        return fail(HF_EINVAL, "hf_reparam_normalization: NULL argument");
-    if (!(kappa > 0.f)) return fail(HF_EINVAL, "hf_reparam_normalization: kappa must be > 0");
-    if (num_rays == 0) return fail(HF_EINVAL, "hf_reparam_normalization: num_rays must be >= 1");
-    if (num_rays > 1 && sample_stride < n) return fail(HF_EINVAL, "hf_reparam_normalization: sample_stride < n");
-    if (n >= ((size_t) 1 << 32)) return fail(HF_EINVAL, "hf_reparam_normalization: more than 2^32 rays");
-    hf_reparam_args a = {};
-    a.n = n; a.active = active; a.seed = seed; a.kappa = kappa; a.exponent = exponent; a.antithetic = antithetic;
-    a.si_t = si_t; a.si_bt = si_boundary_test; a.Z = Z;
-    for (int c = 0; c < 3; ++c) { a.d[c] = d[c]; a.dZ[c] = dZ[c]; }
-    hf_launch_reparam_norm(a, num_rays, sample_stride, (hipStream_t) stream);
-    HF_HIP(hipGetLastError());
-    return HF_OK;
-}
-
-extern "C" int hf_reparam_adjoint(const hf_field_t *hf, size_t n, const float *const o[3], const float *const d[3],
-                                  const uint8_t *active, uint32_t k, float kappa, float exponent, int antithetic,
-                                  uint32_t seed, const hf_pi_const_t *pi, const float *si_boundary_test,
-                                  const float *Z, const float *const dZ[3], const float *const grad_direction[3],
-                                  const float *grad_divergence, float *grad_heights, hf_stream_t stream) {
-    if (!hf) return fail(HF_EINVAL, "hf_reparam_adjoint: NULL handle");
-    if (!all3(o) || !all3(d) || !si_boundary_test || !Z || !all3(dZ) || !all3(grad_direction) || !grad_divergence ||
-        !grad_heights)
-        return fail(HF_EINVAL, "hf_reparam_adjoint: NULL argument");
-    int rc = check_pi("hf_reparam_adjoint", n, pi);
+extern "C" int hf_reparam_backward(const hf_field_t *hf, size_t n, const float *const o[3], const float *const d[3],
+                                   const uint8_t *active, uint32_t num_rays, float kappa, float exponent,
+                                   int antithetic, uint32_t seed, const hf_pi_const_t *pi,
+                                   const float *si_boundary_test, size_t sample_stride,
+                                   const float *const grad_direction[3], const float *grad_divergence,
+                                   float *grad_heights, hf_stream_t stream) {
+    if (!hf) return fail(HF_EINVAL, "hf_reparam_backward: NULL handle");
+    if (!all3(o) || !all3(d) || !si_boundary_test || !all3(grad_direction) || !grad_divergence || !grad_heights)
+        return fail(HF_EINVAL, "hf_reparam_backward: NULL argument");
+    int rc = check_pi("hf_reparam_backward", n, pi);
     if (rc) return rc;
-    if (!(kappa > 0.f)) return fail(HF_EINVAL, "hf_reparam_adjoint: kappa must be > 0");
-    if (n >= ((size_t) 1 << 32)) return fail(HF_EINVAL, "hf_reparam_adjoint: more than 2^32 rays");
-    hf_reparam_args a = {};
-    a.n = n; a.active = active; a.k = k; a.seed = seed; a.kappa = kappa; a.exponent = exponent;
-    a.antithetic = antithetic; a.mode = 1;
-    a.si_bt = si_boundary_test; a.Z = const_cast<float *>(Z); a.g_div = grad_divergence;
-    for (int c = 0; c < 3; ++c) {
-        a.o[c] = o[c]; a.d[c] = d[c]; a.dZ[c] = const_cast<float *>(dZ[c]); a.g_dir[c] = grad_direction[c];
-    }
+    if (!(kappa > 0.f)) return fail(HF_EINVAL, "hf_reparam_backward: kappa must be > 0");
+    if (num_rays == 0 || num_rays > 32) return fail(HF_EINVAL, "hf_reparam_backward: 1..32 auxiliary rays per ray (got %u)", num_rays);
+    if (num_rays > 1 && sample_stride < n) return fail(HF_EINVAL, "hf_reparam_backward: sample_stride < n");
+    if (n >= ((size_t) 1 << 32)) return fail(HF_EINVAL, "hf_reparam_backward: more than 2^32 rays");
     int cur = -1; // like the other query functions: the launch goes to the caller's current device
     if (hipGetDevice(&cur) != hipSuccess || cur != hf->device)
-        return fail(HF_EDEVICE, "hf_reparam_adjoint: current HIP device is %d, the heightfield lives on device %d", cur,
+        return fail(HF_EDEVICE, "hf_reparam_backward: current HIP device is %d, the heightfield lives on device %d", cur,
                     hf->device);
-    hf_launch_reparam_adjoint(hf->dev, a, pi, grad_heights, (hipStream_t) stream);
+    hf_reparam_args a = {};
+    a.n = n; a.active = active; a.seed = seed; a.kappa = kappa; a.exponent = exponent; a.antithetic = antithetic;
+    a.si_bt = si_boundary_test; a.g_div = grad_divergence;
+    for (int c = 0; c < 3; ++c) { a.o[c] = o[c]; a.d[c] = d[c]; a.g_dir[c] = grad_direction[c]; }
+    hf_launch_reparam_backward(hf->dev, a, num_rays, sample_stride, pi, grad_heights, (hipStream_t) stream);
     HF_HIP(hipGetLastError());
     return HF_OK;
 }

@@ -1166,16 +1166,11 @@ struct hf_grad_dev {
 __device__ __forceinline__ float ld(const float *p, size_t i) { return p ? p[i] : 0.f; }
 __device__ __forceinline__ v3 ld3(const float *const p[3], size_t i) { return mk3(ld(p[0], i), ld(p[1], i), ld(p[2], i)); }
 
-// REPARAM: sample ra.k of the second loop of the warped-area reparameterisation (reparam.py:296-325) in one pass --
-// the auxiliary ray is regenerated from the primary ray, (grad_t, grad_p) are mode 1 of hf_reparam_weight_kernel
-// evaluated in registers (rays / g are unused; flags = All | FollowShape | BoundaryTest).
-template <bool REPARAM>
 __global__ __launch_bounds__(HF_BLOCK, 5) void hf_adjoint_kernel(hf_dev_field f, size_t n, hf_rays_dev rays,
                                                               hf_pi_cdev pi, const uint8_t *__restrict__ active,
                                                               hf_grad_dev g, uint32_t flags,
                                                               float *__restrict__ grad_h, float *go0, float *go1,
-                                                              float *go2, float *gd0, float *gd1, float *gd2,
-                                                              hf_reparam_args ra) {
+                                                              float *go2, float *gd0, float *gd1, float *gd2) {
     const bool follow = (flags & 0x80u) != 0, detach = (flags & 0x100u) != 0;
     const bool tex = (flags & (0x2u | 0x4u)) != 0;
     // Wave-level pre-reduction of the scatter: the hits of one wave (one pixel's samples for
@@ -1199,18 +1194,8 @@ __global__ __launch_bounds__(HF_BLOCK, 5) void hf_adjoint_kernel(hf_dev_field f,
         int vr[3] = { 0, 0, 0 }, vc[3] = { 0, 0, 0 };
         bool scatter = false;
         if (act) {
-            v3 o, d;
-            hf_aux_sample q;
-            v3 d_primary;
-            if (REPARAM) {
-                o = mk3(ra.o[0][i], ra.o[1][i], ra.o[2][i]);
-                d_primary = mk3(ra.d[0][i], ra.d[1][i], ra.d[2][i]);
-                aux_sample(ra, i, d_primary, q);
-                d = frame_to_world(q, d_primary, q.omega); // = hf_reparam_aux_kernel's direction
-            } else {
-                o = mk3(rays.o[0][i], rays.o[1][i], rays.o[2][i]);
-                d = mk3(rays.d[0][i], rays.d[1][i], rays.d[2][i]);
-            }
+            const v3 o = mk3(rays.o[0][i], rays.o[1][i], rays.o[2][i]);
+            const v3 d = mk3(rays.d[0][i], rays.d[1][i], rays.d[2][i]);
             const float b1 = pi.u[i], b2 = pi.v[i], b0 = 1.f - b1 - b2;
             const uint32_t prim = pi.prim[i];
             v3 P[3];
@@ -1223,25 +1208,11 @@ __global__ __launch_bounds__(HF_BLOCK, 5) void hf_adjoint_kernel(hf_dev_field f,
                              __builtin_fmaf(P[0].z, b0, __builtin_fmaf(P[1].z, b1, P[2].z * b2)));
             const v3 z3 = mk3(0.f, 0.f, 0.f);
             v3 gP0 = z3, gP1 = z3, gP2 = z3, gdp0 = z3, gdp1 = z3;
-            v3 gp;
-            float gt;
-            if (REPARAM) {
-                float w;
-                v3 dw;
-                reparam_weight(ra, q, d_primary, ra.si_bt[i], w, dw);
-                const v3 gVd = reparam_grad_vdirect(ra, i, d_primary, w, dw);
-                // V_direct = (si.p - o) / si.t with the FollowShape t of compute_si (same expressions: same bits)
-                const v3 po = p - o;
-                const float it = 1.0f / __builtin_sqrtf(dot3(po, po) / dot3(d, d));
-                gp = mk3(gVd.x * it, gVd.y * it, gVd.z * it);
-                gt = -dot3(gVd, po) * it * it;
-            } else {
-                gp = ld3(g.p, i);
-                gt = ld(g.t, i);
-            }
+            v3 gp = ld3(g.p, i);
+            const float gt = ld(g.t, i);
 
             // dp_du / dp_dv from the (constant) texcoord differences
-            if (!REPARAM && (flags & 0x4u)) {
+            if (flags & 0x4u) {
                 const float du0 = U[1] - U[0], dv0 = V[1] - V[0], du1 = U[2] - U[0], dv1 = V[2] - V[0];
                 const float det = __builtin_fmaf(du0, dv1, -(dv0 * du1));
                 const float inv_det = rcp_ieee(det);
@@ -1254,7 +1225,7 @@ __global__ __launch_bounds__(HF_BLOCK, 5) void hf_adjoint_kernel(hf_dev_field f,
                 }
             }
             // n = sh_n = +-normalize(cross(dp0, dp1))
-            if (!REPARAM) {
+            {
                 const v3 N = cross3(dp0, dp1);
                 const float r = rsqrt_ieee(dot3(N, N));
                 const v3 nn = N * r;
@@ -1276,7 +1247,7 @@ __global__ __launch_bounds__(HF_BLOCK, 5) void hf_adjoint_kernel(hf_dev_field f,
                 axpy3(-gt * tt / dd, d, gd);
             }
             // p = sum b_k P_k, uv = sum b_k uv_k
-            const float guv0 = REPARAM ? 0.f : ld(g.uv[0], i), guv1 = REPARAM ? 0.f : ld(g.uv[1], i);
+            const float guv0 = ld(g.uv[0], i), guv1 = ld(g.uv[1], i);
             float gb0 = dot3(gp, P[0]), gb1 = dot3(gp, P[1]), gb2 = dot3(gp, P[2]);
             if (tex) {
                 gb0 += guv0 * U[0] + guv1 * V[0];
@@ -1373,21 +1344,177 @@ void hf_launch_adjoint(const hf_dev_field &f, size_t n, const hf_rays_t *rays, c
         g.dp_du[k] = gs->dp_du[k]; g.dp_dv[k] = gs->dp_dv[k];
     }
     g.uv[0] = gs->uv[0]; g.uv[1] = gs->uv[1];
-    hipLaunchKernelGGL(hf_adjoint_kernel<false>, dim3(grid_for(n)), dim3(HF_BLOCK), 0, stream, f, n, to_dev(rays), p,
-                       active, g, flags, grad_h, grad_o ? grad_o[0] : nullptr, grad_o ? grad_o[1] : nullptr,
+    hipLaunchKernelGGL(hf_adjoint_kernel, dim3(grid_for(n)), dim3(HF_BLOCK), 0, stream, f, n, to_dev(rays), p, active,
+                       g, flags, grad_h, grad_o ? grad_o[0] : nullptr, grad_o ? grad_o[1] : nullptr,
                        grad_o ? grad_o[2] : nullptr, grad_d ? grad_d[0] : nullptr, grad_d ? grad_d[1] : nullptr,
-                       grad_d ? grad_d[2] : nullptr, hf_reparam_args{});
+                       grad_d ? grad_d[2] : nullptr);
 }
 
-void hf_launch_reparam_adjoint(const hf_dev_field &f, const hf_reparam_args &a, const hf_pi_const_t *pi, float *grad_h,
-                               hipStream_t stream) {
-    if (a.n == 0) return;
-    const hf_pi_cdev p = { pi->t, pi->prim_uv[0], pi->prim_uv[1], pi->prim_index };
-    hf_rays_dev nr = {};
-    hf_grad_dev ng = {};
-    const uint32_t flags = 0x1u | 0x2u | 0x4u | 0x8u | 0x10u | 0x20u | 0x40u | 0x80u; // All | BoundaryTest | FollowShape
-    hipLaunchKernelGGL(hf_adjoint_kernel<true>, dim3(grid_for(a.n)), dim3(HF_BLOCK), 0, stream, f, a.n, nr, p, a.active,
-                       ng, flags, grad_h, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, a);
+// ---------------------------------------------------------------------------------
+// Backward of the warped-area reparameterisation with respect to the heights, all auxiliary samples of a ray in ONE
+// pass (reparam.py:224-333 for the shape parameter): the weights of the samples and their sums Z, dZ (first loop,
+// :236-256), then for every auxiliary HIT the gradient of its V_direct = (si.p - o) / si.t through the FollowShape
+// surface interaction to the three heights of the hit triangle (third loop, :296-325).  Nothing but the auxiliary
+// hits (pi + si.boundary_test per sample) is read: the auxiliary direction is regenerated from (d, k, seed), si.p and
+// the FollowShape si.t are re-derived from pi with compute_si's expressions.  A ray none of whose samples hit does
+// not reach the heights and is skipped after its num_rays reads of pi.t.
+// Sample k of ray i sits at [k * stride + i] of every per-sample array.
+// ---------------------------------------------------------------------------------
+struct hf_reparam_bwd_args {
+    size_t n, stride;
+    const float *o[3], *d[3];
+    const uint8_t *active;
+    uint32_t num_rays, seed;
+    float kappa, exponent;
+    int antithetic;
+    const float *pi_t, *pi_u, *pi_v, *si_bt;
+    const uint32_t *pi_prim;
+    const float *g_dir[3], *g_div;
+    float *grad_h;
+};
+
+#ifndef HF_RB_TILE
+#define HF_RB_TILE 64 // the auxiliary hits of a pixel spread over tens of cells: a larger tile than hf_adjoint_kernel's
+#endif
+__global__ __launch_bounds__(HF_BLOCK, (HF_RB_TILE > 32 ? 2 : 5)) void hf_reparam_backward_kernel(hf_dev_field f, hf_reparam_bwd_args a) {
+    __shared__ float s_acc[HF_BLOCK / 64][HF_RB_TILE * HF_RB_TILE]; // per-wave accumulation tile, as in hf_adjoint_kernel
+    float *acc = s_acc[threadIdx.x >> 6];
+    const int lane = (int) (threadIdx.x & 63u);
+    for (int k = lane; k < HF_RB_TILE * HF_RB_TILE; k += 64) acc[k] = 0.f;
+    hf_reparam_args sa = {}; // what the sampling helpers read
+    sa.seed = a.seed; sa.kappa = a.kappa; sa.exponent = a.exponent; sa.antithetic = a.antithetic;
+    const size_t stride = (size_t) gridDim.x * HF_BLOCK;
+    const size_t n_round = (a.n + HF_BLOCK - 1) / HF_BLOCK * HF_BLOCK; // whole waves stay in the loop (ballots below)
+    for (size_t i_raw = (size_t) blockIdx.x * HF_BLOCK + threadIdx.x; i_raw < n_round; i_raw += stride) {
+        const bool valid = i_raw < a.n;
+        const size_t i = valid ? i_raw : a.n - 1;
+        const bool act = valid && (a.active ? (a.active[i] != 0) : true);
+        uint32_t hm = 0u; // samples that hit
+        for (uint32_t k = 0; k < a.num_rays; ++k)
+            hm |= (act && a.pi_t[k * a.stride + i] != __builtin_inff()) ? (1u << k) : 0u;
+        if (__ballot(hm != 0u) == 0ull) continue; // wave-uniform
+        v3 o = mk3(0.f, 0.f, 0.f), d = o, gV = o;
+        float gdivV = 0.f;
+        if (hm != 0u) {
+            o = mk3(a.o[0][i], a.o[1][i], a.o[2][i]);
+            d = mk3(a.d[0][i], a.d[1][i], a.d[2][i]);
+            // first loop: Z = sum_k w_k, dZ = sum_k d_w_omega_k, in sample order from zero
+            float Zs = 0.f;
+            v3 dZ = mk3(0.f, 0.f, 0.f);
+            for (uint32_t k = 0; k < a.num_rays; ++k) {
+                sa.k = k;
+                hf_aux_sample q;
+                aux_sample(sa, i, d, q);
+                const float B = ((hm >> k) & 1u) ? a.si_bt[k * a.stride + i] : 1.0f;
+                float w;
+                v3 dw;
+                reparam_weight(sa, q, d, B, w, dw);
+                Zs += w;
+                dZ.x += dw.x; dZ.y += dw.y; dZ.z += dw.z;
+            }
+            // the part of reparam_grad_vdirect that is common to the samples of a ray
+            const float Z = fmaxf(Zs, 1e-8f), iZ = 1.0f / Z;
+            const v3 gd = mk3(a.g_dir[0][i], a.g_dir[1][i], a.g_dir[2][i]);
+            const float gdiv = a.g_div[i];
+            const float dd = dot3(d, d), idn = 1.0f / __builtin_sqrtf(dd);
+            const float pr = dot3(d, gd) / dd;
+            const float c = gdiv * iZ * iZ;
+            gV = mk3((gd.x - d.x * pr) * idn * iZ - c * dZ.x, (gd.y - d.y * pr) * idn * iZ - c * dZ.y,
+                     (gd.z - d.z * pr) * idn * iZ - c * dZ.z);
+            gdivV = gdiv * iZ;
+        }
+        // third loop: the auxiliary hits, sample by sample (wave-uniform loop, lanes with a hit take part); all
+        // samples of the batch go into the tile before it is flushed
+        int ar = 0, ac = 0;   // tile anchor (wave-uniform), set at the first sample with a hit
+        bool anchored = false;
+        uint64_t rows = 0ull;
+        const uint32_t hm_any = wave_or(hm);
+        for (uint32_t k = 0; k < a.num_rays; ++k) {
+            if (((hm_any >> k) & 1u) == 0u) continue; // wave-uniform
+            const bool hit = ((hm >> k) & 1u) != 0u;
+            float gh[3] = { 0.f, 0.f, 0.f };
+            int vr[3] = { 0, 0, 0 }, vc[3] = { 0, 0, 0 };
+            if (hit) {
+                sa.k = k;
+                hf_aux_sample q;
+                aux_sample(sa, i, d, q);
+                float w;
+                v3 dw;
+                reparam_weight(sa, q, d, a.si_bt[k * a.stride + i], w, dw);
+                const v3 gVd = mk3(__builtin_fmaf(w, gV.x, gdivV * dw.x), __builtin_fmaf(w, gV.y, gdivV * dw.y),
+                                   __builtin_fmaf(w, gV.z, gdivV * dw.z));
+                const v3 da = frame_to_world(q, d, q.omega); // the auxiliary direction (= hf_reparam_aux_kernel's)
+                const float b1 = a.pi_u[k * a.stride + i], b2 = a.pi_v[k * a.stride + i], b0 = 1.f - b1 - b2;
+                v3 P[3];
+                float U[3], V[3];
+                int vi[3], vj[3];
+                prim_world(f, a.pi_prim[k * a.stride + i], P, U, V, vi, vj);
+                const v3 p = mk3(__builtin_fmaf(P[0].x, b0, __builtin_fmaf(P[1].x, b1, P[2].x * b2)),
+                                 __builtin_fmaf(P[0].y, b0, __builtin_fmaf(P[1].y, b1, P[2].y * b2)),
+                                 __builtin_fmaf(P[0].z, b0, __builtin_fmaf(P[1].z, b1, P[2].z * b2)));
+                // V_direct = (p - o) / t with the FollowShape t = sqrt(|p - o|^2 / |d_aux|^2) of compute_si
+                const v3 po = p - o;
+                const float dda = dot3(da, da), tt = __builtin_sqrtf(dot3(po, po) / dda), it = 1.0f / tt;
+                v3 gp = mk3(gVd.x * it, gVd.y * it, gVd.z * it);
+                const float gt = -dot3(gVd, po) * it * it;
+                axpy3(gt / (tt * dda), po, gp); // t's dependence on p (hf_adjoint_kernel, FollowShape branch)
+                // p = sum b_k P_k with detached barycentrics; dP_k/dh_k = s * (third column of to_world)
+                const v3 ez = mk3(f.to_world[2], f.to_world[6], f.to_world[10]);
+                const v3 z3 = mk3(0.f, 0.f, 0.f);
+                v3 gP0 = z3, gP1 = z3, gP2 = z3;
+                axpy3(b0, gp, gP0); axpy3(b1, gp, gP1); axpy3(b2, gp, gP2);
+                gh[0] = f.s * dot3(ez, gP0); gh[1] = f.s * dot3(ez, gP1); gh[2] = f.s * dot3(ez, gP2);
+                vr[0] = vi[0]; vr[1] = vi[1]; vr[2] = vi[2];
+                vc[0] = vj[0]; vc[1] = vj[1]; vc[2] = vj[2];
+            }
+            if (!anchored) { // wave-uniform: the first sample with a hit anchors the tile
+                const int src = __builtin_ctzll(__ballot(hit));
+                ar = __shfl(vr[0], src) - HF_RB_TILE / 4; ac = __shfl(vc[0], src) - HF_RB_TILE / 4;
+                anchored = true;
+            }
+            if (hit) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const int rr = vr[c] - ar, cc = vc[c] - ac;
+                    if ((unsigned) rr < (unsigned) HF_RB_TILE && (unsigned) cc < (unsigned) HF_RB_TILE) {
+                        atomicAdd(acc + rr * HF_RB_TILE + cc, gh[c]);
+                        rows |= 1ull << rr;
+                    } else {
+                        atomicAdd(a.grad_h + (size_t) vr[c] * f.W + vc[c], gh[c]);
+                    }
+                }
+            }
+        }
+        rows = (uint64_t) wave_or((uint32_t) rows) | ((uint64_t) wave_or((uint32_t) (rows >> 32)) << 32);
+#pragma unroll 1
+        while (rows != 0ull) { // flush the touched rows: 64 consecutive tile entries per wave-instruction
+            const int rr = __builtin_ctzll(rows);
+            rows &= rows - 1ull;
+            for (int c0 = 0; c0 < HF_RB_TILE; c0 += 64) {
+                const int cc = c0 + lane;
+                if (cc < HF_RB_TILE) {
+                    const float v = acc[rr * HF_RB_TILE + cc];
+                    if (v != 0.f) {
+                        atomicAdd(a.grad_h + (size_t) (ar + rr) * f.W + (ac + cc), v);
+                        acc[rr * HF_RB_TILE + cc] = 0.f;
+                    }
+                }
+            }
+        }
+    }
+}
+
+void hf_launch_reparam_backward(const hf_dev_field &f, const hf_reparam_args &ra, uint32_t num_rays, size_t stride,
+                                const hf_pi_const_t *pi, float *grad_h, hipStream_t stream) {
+    if (ra.n == 0) return;
+    hf_reparam_bwd_args a = {};
+    a.n = ra.n; a.stride = stride; a.active = ra.active; a.num_rays = num_rays; a.seed = ra.seed; a.kappa = ra.kappa;
+    a.exponent = ra.exponent; a.antithetic = ra.antithetic;
+    for (int c = 0; c < 3; ++c) { a.o[c] = ra.o[c]; a.d[c] = ra.d[c]; a.g_dir[c] = ra.g_dir[c]; }
+    a.g_div = ra.g_div; a.si_bt = ra.si_bt;
+    a.pi_t = pi->t; a.pi_u = pi->prim_uv[0]; a.pi_v = pi->prim_uv[1]; a.pi_prim = pi->prim_index;
+    a.grad_h = grad_h;
+    hipLaunchKernelGGL(hf_reparam_backward_kernel, dim3(grid_for(ra.n)), dim3(HF_BLOCK), 0, stream, f, a);
 }
 
 // ---------------------------------------------------------------------------------
@@ -1545,39 +1672,6 @@ __global__ __launch_bounds__(HF_BLOCK) void hf_reparam_weight_kernel(hf_reparam_
     a.g_p[0][i] = gp.x; a.g_p[1][i] = gp.y; a.g_p[2][i] = gp.z;
     a.g_t[i] = gt;
     if (a.g_vd[0]) { a.g_vd[0][i] = gvd.x; a.g_vd[1][i] = gvd.y; a.g_vd[2][i] = gvd.z; }
-}
-
-// mode 0 of hf_reparam_weight_kernel for all samples of a ray in one pass (reparam.py:236-256): Z = sum_k w_k,
-// dZ = sum_k d_w_omega_k, summed in sample order from zero (= what the per-sample launches leave in memory).
-// si_t / si_bt of sample k are at [k * stride + i].
-__global__ __launch_bounds__(HF_BLOCK) void hf_reparam_norm_kernel(hf_reparam_args a, uint32_t num_rays, size_t stride) {
-    const size_t i = (size_t) blockIdx.x * HF_BLOCK + threadIdx.x;
-    if (i >= a.n) return;
-    const bool act = !(a.active && a.active[i] == 0);
-    float Z = 0.f;
-    v3 dZ = mk3(0.f, 0.f, 0.f);
-    if (act) {
-        const v3 d = mk3(a.d[0][i], a.d[1][i], a.d[2][i]);
-        for (uint32_t k = 0; k < num_rays; ++k) {
-            a.k = k;
-            hf_aux_sample q;
-            aux_sample(a, i, d, q);
-            const bool hit = a.si_t[k * stride + i] != __builtin_inff();
-            const float B = hit ? a.si_bt[k * stride + i] : 1.0f;
-            float w;
-            v3 dw;
-            reparam_weight(a, q, d, B, w, dw);
-            Z += w;
-            dZ.x += dw.x; dZ.y += dw.y; dZ.z += dw.z;
-        }
-    }
-    a.Z[i] = Z;
-    a.dZ[0][i] = dZ.x; a.dZ[1][i] = dZ.y; a.dZ[2][i] = dZ.z;
-}
-void hf_launch_reparam_norm(const hf_reparam_args &a, uint32_t num_rays, size_t stride, hipStream_t stream) {
-    if (a.n == 0) return;
-    hipLaunchKernelGGL(hf_reparam_norm_kernel, dim3((unsigned) ((a.n + HF_BLOCK - 1) / HF_BLOCK)), dim3(HF_BLOCK), 0, stream,
-                       a, num_rays, stride);
 }
 
 void hf_launch_reparam_aux(const hf_reparam_args &a, hipStream_t stream) {

@@ -49,6 +49,5 @@ struct hf_reparam_args {
 };
 void hf_launch_reparam_aux(const hf_reparam_args &a, hipStream_t stream);
 void hf_launch_reparam_weights(const hf_reparam_args &a, hipStream_t stream);
-void hf_launch_reparam_norm(const hf_reparam_args &a, uint32_t num_rays, size_t stride, hipStream_t stream);
-void hf_launch_reparam_adjoint(const hf_dev_field &f, const hf_reparam_args &a, const hf_pi_const_t *pi, float *grad_h,
-                               hipStream_t stream);
+void hf_launch_reparam_backward(const hf_dev_field &f, const hf_reparam_args &a, uint32_t num_rays, size_t stride,
+                                const hf_pi_const_t *pi, float *grad_h, hipStream_t stream);

@@ -727,16 +727,18 @@ class _ReparameterizeOp(torch.autograd.Function):
         keep = 36 * n * num_rays <= (16 << 30)
         store = torch.empty((num_rays if keep else 1, 9, n), dtype=torch.float32, device=dev)
         bufs = [store[k] for k in range(store.shape[0])]
-        # heights only and the hits kept: the two loops run fused (hf_reparam_normalization: mode 0 of all samples in
-        # one pass; hf_reparam_adjoint: auxiliary ray + mode 1 + adjoint of a sample in one kernel)
-        fused = REPARAM_FUSED and keep and not ray_grads
+        # heights only and the hits kept: after the traces ONE kernel does the rest (hf_reparam_backward: the weights of
+        # all samples, their sums, and the adjoint of every auxiliary hit); the traces then only write pi and
+        # si.boundary_test
+        fused = REPARAM_FUSED and keep and not ray_grads and num_rays <= 32
 
         def structs(buf):
             rows = _rows(buf, n)   # si.t, si.p[3], boundary_test | pi.t, u, v, prim_index
             si_s = _capi.hf_si_t()
-            si_s.t = rows[0]
-            for c in range(3):
-                si_s.p[c] = rows[1 + c]
+            if not fused:
+                si_s.t = rows[0]
+                for c in range(3):
+                    si_s.p[c] = rows[1 + c]
             si_s.boundary_test = rows[4]
             pi_s = _capi.hf_pi_t()
             pi_s.t, pi_s.prim_uv[0], pi_s.prim_uv[1], pi_s.prim_index = rows[5], rows[6], rows[7], rows[8]
@@ -764,16 +766,11 @@ class _ReparameterizeOp(torch.autograd.Function):
             trace(k, buf)
             if not fused:
                 weights(0, k, buf)
-        if fused:
-            base = store.data_ptr()
-            check(L.hf_reparam_normalization(n, C.byref(d_p), act_p, num_rays, kappa, exponent, int(antithetic), seed,
-                                             base, base + 4 * 4 * n, 9 * n, Z.data_ptr(), C.byref(dZ_p), stream))
-            if need_h:
-                for k in range(num_rays):   # back-propagation of every sample (reparam.py:296-325)
-                    rows, si_s, pi_s = structs(bufs[k])
-                    check(L.hf_reparam_adjoint(shape._h, n, C.byref(o_p), C.byref(d_p), act_p, k, kappa, exponent,
-                                               int(antithetic), seed, C.byref(pi_s), rows[4], Z.data_ptr(),
-                                               C.byref(dZ_p), C.byref(gd_p), gdiv.data_ptr(), grad_h.data_ptr(), stream))
+        if fused and need_h:
+            rows, si_s, pi_s = structs(bufs[0])   # sample k: the same rows of store[k], 9 n floats further on
+            check(L.hf_reparam_backward(shape._h, n, C.byref(o_p), C.byref(d_p), act_p, num_rays, kappa, exponent,
+                                        int(antithetic), seed, C.byref(pi_s), rows[4], 9 * n, C.byref(gd_p),
+                                        gdiv.data_ptr(), grad_h.data_ptr(), stream))
         for k in range(0 if fused else num_rays):   # the same, per-sample kernels (ray gradients wanted / hits not kept)
             buf = bufs[k if keep else 0]
             if keep:
