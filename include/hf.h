@@ -287,6 +287,13 @@ int hf_reparam_weights(int mode, size_t n, const float *const o[3], const float 
                        float *Z, float *const dZ[3], const float *const grad_direction[3],
                        const float *grad_divergence, float *const grad_p[3], float *grad_t,
                        float *const grad_vd[3], hf_stream_t stream);
+/* hf_reparam_aux_rays + hf_ray_intersect in one launch: traces auxiliary ray k of every ray (o, d) with
+ * HF_RAY_ALL | HF_RAY_FOLLOWSHAPE | HF_RAY_BOUNDARYTEST (reparam.py:93-95) without materialising the auxiliary rays;
+ * inactive lanes are misses.  out_pi / out_si as in hf_ray_intersect (si.wi is expressed for the auxiliary direction).
+ * Bitwise the two-call sequence. */
+int hf_reparam_trace(const hf_field_t *hf, size_t n, const float *const o[3], const float *const d[3],
+                     const uint8_t *active, uint32_t k, float kappa, int antithetic, uint32_t seed,
+                     const hf_pi_t *out_pi, const hf_si_t *out_si, hf_stream_t stream);
 /* The same backward pass in ONE kernel for the case that only the heights are differentiated (grad(ray) not wanted):
  * for every ray the weights of its num_rays samples and their sums Z, dZ (reparam.py:236-256), then for every
  * auxiliary HIT the gradient of its V_direct through the FollowShape surface interaction into grad_heights[H*W]

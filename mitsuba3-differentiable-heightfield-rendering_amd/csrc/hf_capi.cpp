@@ -539,6 +539,32 @@ extern "C" int hf_reparam_weights(int mode, size_t n, const float *const o[3], c
     return HF_OK;
 }
 
+extern "C" int hf_reparam_trace(const hf_field_t *hf, size_t n, const float *const o[3], const float *const d[3],
+                                const uint8_t *active, uint32_t k, float kappa, int antithetic, uint32_t seed,
+                                const hf_pi_t *out_pi, const hf_si_t *out_si, hf_stream_t stream) {
+    if (!all3(o) || !all3(d)) return fail(HF_EINVAL, "hf_reparam_trace: NULL argument");
+    hf_rays_t rays; // maxt is not read for auxiliary rays (infinity); any readable array of n floats will do
+    for (int c = 0; c < 3; ++c) { rays.o[c] = o[c]; rays.d[c] = d[c]; }
+    rays.maxt = o[0];
+    int rc = check_rays("hf_reparam_trace", hf, n, &rays);
+    if (rc) return rc;
+    if (!out_si) return fail(HF_EINVAL, "hf_reparam_trace: NULL output");
+    if (!(kappa > 0.f)) return fail(HF_EINVAL, "hf_reparam_trace: kappa must be > 0");
+    if (n >= ((size_t) 1 << 32)) return fail(HF_EINVAL, "hf_reparam_trace: more than 2^32 rays");
+    hf_reparam_args a = {};
+    a.k = k; a.seed = seed; a.kappa = kappa; a.antithetic = antithetic;
+    {
+        uint32_t slot;
+        void *counter = slot_acquire(hf, (hipStream_t) stream, hf_trace_scratch_bytes(n), &slot);
+        if (!counter) return fail(HF_ENOMEM, "trace launch: scratch allocation failed");
+        hf_launch_trace(2, hf->dev, n, &rays, active, out_pi, nullptr, out_si,
+                        HF_RAY_ALL | HF_RAY_FOLLOWSHAPE | HF_RAY_BOUNDARYTEST, counter, (hipStream_t) stream, &a);
+        slot_release(hf, (hipStream_t) stream, slot);
+    }
+    HF_HIP(hipGetLastError());
+    return HF_OK;
+}
+
 extern "C" int hf_reparam_backward(const hf_field_t *hf, size_t n, const float *const o[3], const float *const d[3],
                                    const uint8_t *active, uint32_t num_rays, float kappa, float exponent,
                                    int antithetic, uint32_t seed, const hf_pi_const_t *pi,

@@ -674,6 +674,48 @@ __device__ __forceinline__ void walk_rows(const hf_dev_field &f, const hf_ray_st
 #endif
 }
 
+// ---------------------------------------------------------------------------------
+// Warped-area reparameterisation (include/hf.h; reparam.py:10-123,224-333): per-sample kernels
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ void tea32(uint32_t v0, uint32_t v1, uint32_t &o0, uint32_t &o1) { // random.h:76-91
+    uint32_t sum = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        sum += 0x9e3779b9u;
+        v0 += ((v1 << 4) + 0xa341316cu) ^ (v1 + sum) ^ ((v1 >> 5) + 0xc8013ea4u);
+        v1 += ((v0 << 4) + 0xad90777du) ^ (v0 + sum) ^ ((v0 >> 5) + 0x7e95761eu);
+    }
+    o0 = v0; o1 = v1;
+}
+
+struct hf_aux_sample {
+    v3 omega;     // square_to_von_mises_fisher(sample, kappa), xy negated on the flipped half of a pair
+    float sy;     // sample.y
+    v3 fs, ft;    // Frame3f(d): s, t (n = d)
+};
+__device__ __forceinline__ void aux_sample(const hf_reparam_args &a, size_t i, v3 d, hf_aux_sample &q) {
+    const uint32_t pair = a.antithetic ? (a.k >> 1) : a.k;
+    uint32_t r0, r1;
+    tea32(a.seed + pair, (uint32_t) i, r0, r1);
+    const float sx = (float) (r0 >> 9) * (1.0f / 8388608.0f), sy = (float) (r1 >> 9) * (1.0f / 8388608.0f);
+    // warp.h:557-566
+    const float syc = fmaxf(1.f - sy, 1e-6f);
+    const float cos_theta = 1.f + logf(__builtin_fmaf(1.f - syc, expf(-2.f * a.kappa), syc)) / a.kappa;
+    float sn, cs;
+    sincospif(2.f * sx, &sn, &cs); // sin / cos of 2 pi sx without the range reduction of a radian argument
+    const float sin_theta = __builtin_sqrtf(fmaxf(1.f - cos_theta * cos_theta, 0.f));
+    const bool flip = a.antithetic && ((a.k & 1u) == 0u); // reparam.py:83-85,189
+    q.omega = mk3(flip ? -(cs * sin_theta) : cs * sin_theta, flip ? -(sn * sin_theta) : sn * sin_theta, cos_theta);
+    q.sy = sy;
+    coordinate_system(d, q.fs, q.ft);
+}
+// Frame3f::to_world (frame.h:39-41)
+__device__ __forceinline__ v3 frame_to_world(const hf_aux_sample &q, v3 n, v3 v) {
+    return mk3(__builtin_fmaf(n.x, v.z, __builtin_fmaf(q.ft.x, v.y, q.fs.x * v.x)),
+               __builtin_fmaf(n.y, v.z, __builtin_fmaf(q.ft.y, v.y, q.fs.y * v.x)),
+               __builtin_fmaf(n.z, v.z, __builtin_fmaf(q.ft.z, v.y, q.fs.z * v.x)));
+}
+
 struct hf_rays_dev {
     const float *o[3];
     const float *d[3];
@@ -751,6 +793,11 @@ struct hf_trace_args {
     uint32_t grab; // rays per fetch, a multiple of 64
     unsigned long long *counter;
     unsigned long long n_grabs; // ceil(n / grab)
+    // fused mode only: trace auxiliary ray aux_k of every ray instead of the ray itself (hf_reparam_trace): the
+    // direction is replaced by hf_reparam_aux_kernel's, maxt by infinity
+    uint32_t aux_on, aux_k, aux_seed;
+    float aux_kappa;
+    int aux_antithetic;
 };
 
 // member-wise copy out of the kernarg segment (constant address space)
@@ -874,6 +921,14 @@ __global__ __launch_bounds__(HF_BLOCK, (MODE == 2 ? HF_TRACE_WAVES_FUSED : HF_TR
                 o = mk3((rp.o[0] + ub)[lo], (rp.o[1] + ub)[lo], (rp.o[2] + ub)[lo]);
                 d = mk3((rp.d[0] + ub)[lo], (rp.d[1] + ub)[lo], (rp.d[2] + ub)[lo]);
                 maxt = (rp.maxt + ub)[lo];
+            }
+            if (MODE == 2 && ka->aux_on != 0u) { // wave-uniform
+                hf_reparam_args sa = {};
+                sa.k = ka->aux_k; sa.seed = ka->aux_seed; sa.kappa = ka->aux_kappa; sa.antithetic = ka->aux_antithetic;
+                hf_aux_sample q;
+                aux_sample(sa, ub + lo, d, q);
+                d = frame_to_world(q, d, q.omega);
+                maxt = __builtin_inff();
             }
             hf_hit best;
             best.hit = false; best.t = __builtin_inff(); best.u = 0.f; best.v = 0.f; best.prim = 0u;
@@ -1015,7 +1070,7 @@ size_t hf_trace_scratch_bytes(size_t n) {
 
 void hf_launch_trace(int mode, const hf_dev_field &f, size_t n, const hf_rays_t *rays, const uint8_t *active,
                      const hf_pi_t *pi, uint8_t *hit, const hf_si_t *si, uint32_t flags, void *scratch,
-                     hipStream_t stream) {
+                     hipStream_t stream, const hf_reparam_args *aux) {
     if (n == 0) return;
     (void) hipMemsetAsync(scratch, 0, HF_SCR_BYTES, stream);
     hf_pi_dev p = { nullptr, nullptr, nullptr, nullptr };
@@ -1033,6 +1088,10 @@ void hf_launch_trace(int mode, const hf_dev_field &f, size_t n, const hf_rays_t 
     a.f = f; a.n = n; a.rays = r; a.active = active; a.pi = p; a.hit_out = hit; a.sio = sd; a.flags = flags;
     a.counter = (unsigned long long *) scratch; a.grab = grab;
     a.n_grabs = waves;
+    a.aux_on = 0u; a.aux_k = 0u; a.aux_seed = 0u; a.aux_kappa = 1.f; a.aux_antithetic = 0;
+    if (aux && mode == 2) {
+        a.aux_on = 1u; a.aux_k = aux->k; a.aux_seed = aux->seed; a.aux_kappa = aux->kappa; a.aux_antithetic = aux->antithetic;
+    }
     if (mode == 0)
         hipLaunchKernelGGL(hf_trace_kernel<0>, grid, block, 0, stream, a);
     else if (mode == 1)
@@ -1087,48 +1146,6 @@ __device__ __forceinline__ uint32_t wave_or(uint32_t v) {
     x |= __builtin_amdgcn_update_dpp(0, x, 0x140, 0xF, 0xF, true); // row_mirror
     return (uint32_t) (__builtin_amdgcn_readlane(x, 0) | __builtin_amdgcn_readlane(x, 16) |
                        __builtin_amdgcn_readlane(x, 32) | __builtin_amdgcn_readlane(x, 48));
-}
-
-// ---------------------------------------------------------------------------------
-// Warped-area reparameterisation (include/hf.h; reparam.py:10-123,224-333): per-sample kernels
-// ---------------------------------------------------------------------------------
-__device__ __forceinline__ void tea32(uint32_t v0, uint32_t v1, uint32_t &o0, uint32_t &o1) { // random.h:76-91
-    uint32_t sum = 0;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        sum += 0x9e3779b9u;
-        v0 += ((v1 << 4) + 0xa341316cu) ^ (v1 + sum) ^ ((v1 >> 5) + 0xc8013ea4u);
-        v1 += ((v0 << 4) + 0xad90777du) ^ (v0 + sum) ^ ((v0 >> 5) + 0x7e95761eu);
-    }
-    o0 = v0; o1 = v1;
-}
-
-struct hf_aux_sample {
-    v3 omega;     // square_to_von_mises_fisher(sample, kappa), xy negated on the flipped half of a pair
-    float sy;     // sample.y
-    v3 fs, ft;    // Frame3f(d): s, t (n = d)
-};
-__device__ __forceinline__ void aux_sample(const hf_reparam_args &a, size_t i, v3 d, hf_aux_sample &q) {
-    const uint32_t pair = a.antithetic ? (a.k >> 1) : a.k;
-    uint32_t r0, r1;
-    tea32(a.seed + pair, (uint32_t) i, r0, r1);
-    const float sx = (float) (r0 >> 9) * (1.0f / 8388608.0f), sy = (float) (r1 >> 9) * (1.0f / 8388608.0f);
-    // warp.h:557-566
-    const float syc = fmaxf(1.f - sy, 1e-6f);
-    const float cos_theta = 1.f + logf(__builtin_fmaf(1.f - syc, expf(-2.f * a.kappa), syc)) / a.kappa;
-    float sn, cs;
-    sincospif(2.f * sx, &sn, &cs); // sin / cos of 2 pi sx without the range reduction of a radian argument
-    const float sin_theta = __builtin_sqrtf(fmaxf(1.f - cos_theta * cos_theta, 0.f));
-    const bool flip = a.antithetic && ((a.k & 1u) == 0u); // reparam.py:83-85,189
-    q.omega = mk3(flip ? -(cs * sin_theta) : cs * sin_theta, flip ? -(sn * sin_theta) : sn * sin_theta, cos_theta);
-    q.sy = sy;
-    coordinate_system(d, q.fs, q.ft);
-}
-// Frame3f::to_world (frame.h:39-41)
-__device__ __forceinline__ v3 frame_to_world(const hf_aux_sample &q, v3 n, v3 v) {
-    return mk3(__builtin_fmaf(n.x, v.z, __builtin_fmaf(q.ft.x, v.y, q.fs.x * v.x)),
-               __builtin_fmaf(n.y, v.z, __builtin_fmaf(q.ft.y, v.y, q.fs.y * v.x)),
-               __builtin_fmaf(n.z, v.z, __builtin_fmaf(q.ft.z, v.y, q.fs.z * v.x)));
 }
 
 // harmonic weight of one auxiliary sample and its gradient w.r.t. the sampled direction (reparam.py:103-121)

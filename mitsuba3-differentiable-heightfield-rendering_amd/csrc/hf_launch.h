@@ -10,9 +10,11 @@ void hf_launch_build_mips(const hf_dev_field &f, float2 *mip, float4 *shear, hip
 // bytes, exclusively this launch's until it has completed
 size_t hf_trace_scratch_bytes(size_t n);
 // mode 0: closest hit -> pi; 1: any hit -> hit; 2: closest hit + fused surface interaction
+struct hf_reparam_args;
+// aux (mode 2 only, may be NULL): trace auxiliary ray aux->k of every ray (k, seed, kappa, antithetic are read)
 void hf_launch_trace(int mode, const hf_dev_field &f, size_t n, const hf_rays_t *rays, const uint8_t *active,
                      const hf_pi_t *pi, uint8_t *hit, const hf_si_t *si, uint32_t flags, void *scratch,
-                     hipStream_t stream);
+                     hipStream_t stream, const hf_reparam_args *aux = nullptr);
 void hf_launch_si(const hf_dev_field &f, size_t n, const hf_rays_t *rays, const hf_pi_const_t *pi,
                   const uint8_t *active, const hf_si_t *si, uint32_t flags, hipStream_t stream);
 void hf_launch_adjoint(const hf_dev_field &f, size_t n, const hf_rays_t *rays, const hf_pi_const_t *pi,

@@ -749,8 +749,12 @@ class _ReparameterizeOp(torch.autograd.Function):
                                         C.byref(ad_p), aux_maxt.data_ptr(), stream))
 
         def trace(k, buf):
-            aux(k)
             rows, si_s, pi_s = structs(buf)
+            if fused:   # auxiliary ray generated inside the trace kernel
+                check(L.hf_reparam_trace(shape._h, n, C.byref(o_p), C.byref(d_p), act_p, k, kappa, int(antithetic), seed,
+                                         C.byref(pi_s), C.byref(si_s), stream))
+                return
+            aux(k)
             check(L.hf_ray_intersect(shape._h, n, C.byref(r_s), flags, None, C.byref(pi_s), C.byref(si_s), stream))
 
         def weights(mode, k, buf):

@@ -116,6 +116,56 @@ def test_gpu_fused_loops_equal_the_per_sample_kernels(hf, kappa, antithetic, num
 
 
 @pytest.mark.gpu
+def test_gpu_reparam_trace_equals_aux_rays_plus_ray_intersect(hf):
+    """hf_reparam_trace (auxiliary ray generated inside the traversal kernel) is bitwise hf_reparam_aux_rays followed by
+    hf_ray_intersect(All | FollowShape | BoundaryTest), inactive lanes included."""
+    import ctypes as C
+    import torch
+    from hf_amd import _capi
+    L = _capi.lib()
+    rng = np.random.default_rng(21)
+    W, H = 130, 97
+    u = np.arange(W) / (W - 1.0); v = np.arange(H)[:, None] / (H - 1.0)
+    h = (0.5 + 0.3 * np.sin(2 * np.pi * 1.5 * u) * np.cos(2 * np.pi * 1.2 * v) + 0.03 * rng.uniform(-1, 1, (H, W))).astype(np.float32)
+    shape = hf.Heightfield(heightfield=torch.from_numpy(h).cuda(), max_height=0.5)
+    n = 30011
+    o, d = _rays(n, rng)
+    ot, dt = torch.from_numpy(o).cuda(), torch.from_numpy(d).cuda()
+    act = torch.from_numpy((rng.uniform(size=n) < 0.85).astype(np.uint8)).cuda()
+    p3 = lambda x: (C.c_void_p * 3)(x[0].data_ptr(), x[1].data_ptr(), x[2].data_ptr())
+    flags = int(hf.RayFlags.All | hf.RayFlags.FollowShape | hf.RayFlags.BoundaryTest)
+
+    def out():
+        buf = torch.full((30, n), float("nan"), device="cuda")
+        rows = [buf[k].data_ptr() for k in range(30)]
+        si = _capi.hf_si_t()
+        si.t = rows[0]; si.boundary_test = rows[1]
+        for c in range(3):
+            si.p[c], si.n[c], si.sh_n[c], si.dp_du[c] = rows[2 + c], rows[5 + c], rows[8 + c], rows[11 + c]
+            si.dp_dv[c], si.sh_s[c], si.sh_t[c], si.wi[c] = rows[14 + c], rows[17 + c], rows[20 + c], rows[23 + c]
+        si.uv[0], si.uv[1] = rows[26], rows[27]
+        pib = torch.full((4, n), float("nan"), device="cuda")
+        pi = _capi.hf_pi_t()
+        pi.t, pi.prim_uv[0], pi.prim_uv[1], pi.prim_index = (pib[k].data_ptr() for k in range(4))
+        return buf, si, pib, pi
+
+    for k, kappa, anti in [(0, 30.0, False), (3, 500.0, True), (2, 1e5, True)]:
+        buf1, si1, pib1, pi1 = out()
+        _capi.check(L.hf_reparam_trace(shape._h, n, C.byref(p3(ot)), C.byref(p3(dt)), act.data_ptr(), k, kappa, int(anti),
+                                       5, C.byref(pi1), C.byref(si1), None))
+        ad = torch.empty_like(dt); mt = torch.empty(n, device="cuda")
+        _capi.check(L.hf_reparam_aux_rays(n, C.byref(p3(ot)), C.byref(p3(dt)), act.data_ptr(), k, kappa, int(anti), 5,
+                                          C.byref(p3(ad)), mt.data_ptr(), None))
+        buf2, si2, pib2, pi2 = out()
+        rs = shape._rays_struct(ot, ad, mt)
+        _capi.check(L.hf_ray_intersect(shape._h, n, C.byref(rs), flags, None, C.byref(pi2), C.byref(si2), None))
+        torch.cuda.synchronize()
+        assert torch.equal(pib1.view(torch.int32), pib2.view(torch.int32))
+        assert torch.equal(buf1[:28].view(torch.int32), buf2[:28].view(torch.int32))
+        assert bool(torch.isfinite(pib1[0]).any()) and not bool(torch.isfinite(pib1[0][act == 0]).any())
+
+
+@pytest.mark.gpu
 def test_gpu_aux_rays_match_oracle(hf, oracle):
     import ctypes as C
     import torch
