@@ -219,7 +219,7 @@ def main():
                     "algorithmic_bytes": {"forward": fwd_bytes, "adjoint": adj_bytes}}
         extras = None
         if world == 1 and os.environ.get("HF_BENCH_EXTRAS", "1") != "0":  # profile_round.sh switches them off
-            extras = other_launches(torch, hf_amd, _capi, lib, shape, r_s, pi_s, si_s, si, R, stream, flags)
+            extras = other_launches(torch, hf_amd, _capi, lib, shape, rays, r_s, pi_s, si_s, si, R, stream, flags)
         cpu = None
         if world == 1 and args.cpu_seconds > 0:
             cpu = cpu_baseline(args, heights.cpu().numpy(), rays, gsi, R)
@@ -247,7 +247,7 @@ def _rows_of(buf, n):
     return [buf.data_ptr() + 4 * n * k for k in range(buf.shape[0])]
 
 
-def other_launches(torch, hf_amd, _capi, lib, shape, r_s, pi_s, si_s, si, R, stream, flags, iters=3):
+def other_launches(torch, hf_amd, _capi, lib, shape, rays, r_s, pi_s, si_s, si, R, stream, flags, iters=3):
     """Not part of `value`: the other entry points of the path on the same wavefront, and on the incoherent
     secondary rays of SURVEY 8d (one cosine bounce + one shadow ray per primary hit), HIP-event ms per launch."""
     dev = si.device
@@ -297,6 +297,30 @@ def other_launches(torch, hf_amd, _capi, lib, shape, r_s, pi_s, si_s, si, R, str
             _capi.check(f())
         e1.record(); torch.cuda.synchronize()
         out[name] = round(e0.elapsed_time(e1) / iters, 4)
+    # backward of mitsuba.ad.reparameterize_ray on the wavefront (reparam.py's defaults: 4 auxiliary
+    # rays per ray, kappa 1e5, exponent 3): 4 x hf_reparam_trace + hf_reparam_backward through the host mirror
+    try:
+        ray = hf_amd.Ray3f(rays[0:3], rays[3:6])
+        gdir = torch.randn(3, R, device=dev); gdv = torch.randn(R, device=dev)
+        was = shape.heightfield.requires_grad
+        shape.heightfield.requires_grad_(True)
+
+        def rp():
+            shape.heightfield.grad = None
+            dd_, det = hf_amd.reparameterize_ray(shape, ray, num_rays=4, kappa=1e5, exponent=3.0)
+            ((dd_ * gdir).sum() + (det * gdv).sum()).backward()
+        rp(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(2):
+            rp()
+        e1.record(); torch.cuda.synchronize()
+        out["reparameterize_ray_backward(4 aux rays)"] = round(e0.elapsed_time(e1) / 2, 3)
+        shape.heightfield.grad = None
+        shape.heightfield.requires_grad_(was)
+        del ray, gdir, gdv
+    except Exception as e:
+        out["reparameterize_ray_backward(4 aux rays)"] = {"error": repr(e)}
     # secondary rays last: they overwrite pi / si of the primary wavefront
     sec = {
         "bounce_rays_ray_intersect": lambda: lib.hf_ray_intersect(shape._h, Rs, C.byref(b_s), flags, None, C.byref(pi_s), C.byref(si_s), stream),
