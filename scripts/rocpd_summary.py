@@ -11,11 +11,17 @@ if mode == "stats":
     for name, calls, total, avg, pct in db.execute("select name,total_calls,total_duration,average,percentage from top_kernels order by total_duration desc"):
         print(f'"{name[:100]}",{calls},{total / 1e6:.4f},{avg / 1e6:.5f},{pct:.2f}')
 elif mode == "stats_ms":
-    print("kernel,calls,total_ms,avg_ms,percent")
-    rows = list(db.execute("select name,count(*),sum(end-start),avg(end-start) from kernels group by name order by sum(end-start) desc"))
-    tot = sum(r[2] for r in rows)
-    for name, calls, total, avg in rows:
-        print(f'"{name[:100]}",{calls},{total / 1e6:.4f},{avg / 1e6:.5f},{100 * total / tot:.2f}')
+    # avg over all launches (cold first launches included) + min and median, which show the steady state
+    print("kernel,calls,total_ms,avg_ms,percent,min_ms,median_ms")
+    durs = {}
+    for name, d in db.execute("select name,end-start from kernels"):
+        durs.setdefault(name, []).append(d)
+    tot = sum(sum(v) for v in durs.values())
+    for name, v in sorted(durs.items(), key=lambda kv: -sum(kv[1])):
+        v.sort()
+        med = v[len(v) // 2] if len(v) % 2 else 0.5 * (v[len(v) // 2 - 1] + v[len(v) // 2])
+        print(f'"{name[:100]}",{len(v)},{sum(v) / 1e6:.4f},{sum(v) / len(v) / 1e6:.5f},{100 * sum(v) / tot:.2f},'
+              f'{v[0] / 1e6:.5f},{med / 1e6:.5f}')
 else:
     subs = sys.argv[3:]
     print("kernel,dispatch,counter,value")
