@@ -12,7 +12,7 @@ def first(path, kernel, counter):
 res = {"_how": "scripts/profile_round.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE in SEPARATE passes over "
                "`python scripts/prof_kernels.py --iters 1 fwd adj miss`; KiB; FETCH_SIZE x2 (gfx950), WRITE_SIZE exact.",
        "source": tag}
-f = first(f"{out}/pmc_FETCH_SIZE.csv", "hf_trace_kernel<2>", "FETCH_SIZE"); w = first(f"{out}/pmc_WRITE_SIZE.csv", "hf_trace_kernel<2>", "WRITE_SIZE")
+f = first(f"{out}/pmc_FETCH_SIZE.csv", "hf_trace_kernel<2", "FETCH_SIZE"); w = first(f"{out}/pmc_WRITE_SIZE.csv", "hf_trace_kernel<2", "WRITE_SIZE")
 # dispatch order of prof_kernels: warm-up fwd, fwd (x iters+1), ..., the last trace<2> launches are the all-miss ones
 fwd_f, fwd_w, miss_f = f[0], w[0], f[-1]
 res["calibration"] = {"all_miss_FETCH_SIZE_KiB": miss_f, "all_miss_read_bytes_exact": 28.0 * R, "ratio": 28.0 * R / (miss_f * 1024)}
