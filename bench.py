@@ -110,15 +110,19 @@ def main():
     def forward():
         _capi.check(lib.hf_ray_intersect(shape._h, R, C.byref(r_s), flags, None, C.byref(pi_s), C.byref(si_s), stream))
 
-    def adjoint():
+    def adjoint(events=None):
         b = step_no[0] % len(grads)
         step_no[0] += 1
         if pending[b] is not None:        # the all-reduce that used this buffer two steps ago
             pending[b].wait(); pending[b] = None
         grad_h = grads[b]
         grad_h.zero_()
+        if events:                        # the kernel alone: not the wait for an earlier all-reduce, not the memset
+            events[0].record()
         _capi.check(lib.hf_adjoint(shape._h, R, C.byref(r_s), C.byref(pi_s), flags, None, C.byref(g_s),
                                    grad_h.data_ptr(), None, None, stream))
+        if events:
+            events[1].record()
         if world > 1:                     # one collective per step, overlapping the next step's kernels
             pending[b] = dist.all_reduce(grad_h, async_op=True)
         return grad_h
@@ -142,9 +146,9 @@ def main():
 
     def step(record):
         if record:
-            a, b, c = ev(), ev(), ev()
-            a.record(); forward(); b.record(); adjoint(); c.record()
-            fwd_ev.append((a, b)); adj_ev.append((b, c))
+            a, b, c, d = ev(), ev(), ev(), ev()
+            a.record(); forward(); b.record(); adjoint((c, d))
+            fwd_ev.append((a, b)); adj_ev.append((c, d))
         else:
             forward(); adjoint()
 
@@ -201,7 +205,7 @@ def main():
         # counter-measured HBM traffic of that kernel, only when the profile it came from was taken at this commit
         traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and world == 1:   # the profile is of the N = 1 launch (the whole wavefront)
             try:
                 tj = json.load(open(tpath))
                 traffic = tj.get(dom_name, {}).get("hbm_bytes_per_launch")
