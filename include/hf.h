@@ -250,6 +250,26 @@ int hf_direct_lighting_adjoint(size_t n, uint32_t spp, const float *const sh_n[3
                                const uint8_t *const *vis, const float *grad_image, float *const grad_sh_n[3],
                                hf_stream_t stream);
 
+/* The same under POINT lights (src/emitters/point.cpp:106-123: direction d = position - si.p, radiance
+ * intensity / |d|^2): sample value albedo/pi * intensity / r^2 * max(0, <sh_n, l>) with l = (position - p) / r, same
+ * masks and film.  p: si.p, 3 device arrays of n floats.  The adjoint returns the gradient with respect to sh_n AND
+ * to p (the light direction and the falloff depend on the hit point):
+ *   grad_sh_n[i] = sum_k w_k / r^2 * l,   grad_p[i] = sum_k w_k / r^3 * (3 <sh_n, l> l - sh_n),
+ *   w_k = 1/spp * albedo/pi * intensity_k * vis_k * grad_image[k][i / spp]            (same masks)
+ * both overwritten; feed them to hf_adjoint as hf_si_grad_t.sh_n / .p. */
+typedef struct {
+    float position[3];
+    float intensity; /* radiant intensity (W/sr) */
+} hf_point_light_t;
+int hf_point_lighting(size_t n, uint32_t spp, const float *const sh_n[3], const float *const d[3], const float *t,
+                      const float *const p[3], uint32_t n_lights, const hf_point_light_t *lights, float albedo,
+                      const uint8_t *const *vis, float *image, hf_stream_t stream);
+int hf_point_lighting_adjoint(size_t n, uint32_t spp, const float *const sh_n[3], const float *const d[3],
+                              const float *t, const float *const p[3], uint32_t n_lights,
+                              const hf_point_light_t *lights, float albedo, const uint8_t *const *vis,
+                              const float *grad_image, float *const grad_sh_n[3], float *const grad_p[3],
+                              hf_stream_t stream);
+
 /* ---- next row: warped-area reparameterisation of rays ---------- */
 
 /* The auxiliary-ray machinery of mitsuba.ad.reparameterize_ray (src/python/python/ad/reparam.py:10-123,

@@ -470,7 +470,7 @@ extern "C" int hf_direct_lighting(size_t n, uint32_t spp, const float *const sh_
     const int rc = pack_lights("hf_direct_lighting", n, spp, sh_n, d, t, n_lights, lights, albedo, vis, L);
     if (rc != HF_OK) return rc;
     if (!image) return fail(HF_EINVAL, "hf_direct_lighting: NULL image");
-    hf_launch_direct(n, spp, sh_n, d, t, L, image, (hipStream_t) stream);
+    hf_launch_direct(n, spp, sh_n, d, t, nullptr, L, image, (hipStream_t) stream);
     HF_HIP(hipGetLastError());
     return HF_OK;
 }
@@ -484,13 +484,48 @@ extern "C" int hf_direct_lighting_adjoint(size_t n, uint32_t spp, const float *c
     if (rc != HF_OK) return rc;
     if (!grad_image || !grad_sh_n || !grad_sh_n[0] || !grad_sh_n[1] || !grad_sh_n[2])
         return fail(HF_EINVAL, "hf_direct_lighting_adjoint: NULL gradient array");
-    hf_launch_direct_adjoint(n, spp, sh_n, d, t, L, grad_image, grad_sh_n, (hipStream_t) stream);
+    hf_launch_direct_adjoint(n, spp, sh_n, d, t, nullptr, L, grad_image, grad_sh_n, nullptr, (hipStream_t) stream);
+    HF_HIP(hipGetLastError());
+    return HF_OK;
+}
+
+static bool all3(const float *const p[3]) { return p && p[0] && p[1] && p[2]; }
+
+// point lights: same packing (hf_point_light_t has hf_dir_light_t's layout: three floats + one)
+extern "C" int hf_point_lighting(size_t n, uint32_t spp, const float *const sh_n[3], const float *const d[3],
+                                 const float *t, const float *const p[3], uint32_t n_lights,
+                                 const hf_point_light_t *lights, float albedo, const uint8_t *const *vis, float *image,
+                                 hf_stream_t stream) {
+    static_assert(sizeof(hf_point_light_t) == sizeof(hf_dir_light_t), "light structs share one packing");
+    hf_lights_dev L;
+    const int rc = pack_lights("hf_point_lighting", n, spp, sh_n, d, t, n_lights, (const hf_dir_light_t *) lights, albedo, vis, L);
+    if (rc != HF_OK) return rc;
+    if (!all3(p)) return fail(HF_EINVAL, "hf_point_lighting: NULL position array");
+    if (!image) return fail(HF_EINVAL, "hf_point_lighting: NULL image");
+    hf_launch_direct(n, spp, sh_n, d, t, p, L, image, (hipStream_t) stream);
+    HF_HIP(hipGetLastError());
+    return HF_OK;
+}
+
+extern "C" int hf_point_lighting_adjoint(size_t n, uint32_t spp, const float *const sh_n[3], const float *const d[3],
+                                         const float *t, const float *const p[3], uint32_t n_lights,
+                                         const hf_point_light_t *lights, float albedo, const uint8_t *const *vis,
+                                         const float *grad_image, float *const grad_sh_n[3], float *const grad_p[3],
+                                         hf_stream_t stream) {
+    hf_lights_dev L;
+    const int rc = pack_lights("hf_point_lighting_adjoint", n, spp, sh_n, d, t, n_lights, (const hf_dir_light_t *) lights,
+                               albedo, vis, L);
+    if (rc != HF_OK) return rc;
+    if (!all3(p)) return fail(HF_EINVAL, "hf_point_lighting_adjoint: NULL position array");
+    if (!grad_image || !grad_sh_n || !grad_sh_n[0] || !grad_sh_n[1] || !grad_sh_n[2] || !grad_p || !grad_p[0] ||
+        !grad_p[1] || !grad_p[2])
+        return fail(HF_EINVAL, "hf_point_lighting_adjoint: NULL gradient array");
+    hf_launch_direct_adjoint(n, spp, sh_n, d, t, p, L, grad_image, grad_sh_n, grad_p, (hipStream_t) stream);
     HF_HIP(hipGetLastError());
     return HF_OK;
 }
 
 // ---- warped-area reparameterisation --------------------------------------------
-static bool all3(const float *const p[3]) { return p && p[0] && p[1] && p[2]; }
 
 extern "C" int hf_reparam_aux_rays(size_t n, const float *const o[3], const float *const d[3], const uint8_t *active,
                                    uint32_t k, float kappa, int antithetic, uint32_t seed, float *const aux_d[3],

@@ -1571,8 +1571,11 @@ void hf_launch_adam(size_t n, float *h, const float *g, float *m, float *v, floa
 struct hf_f3ptr { const float *p[3]; };
 struct hf_f3out { float *p[3]; };
 
+// POINT: L.l[k] is the light's position and L.w[k] = albedo/pi * intensity; the direction towards the light and the
+// inverse-square falloff are per sample (src/emitters/point.cpp: d = pos - it.p, spec = intensity / |d|^2)
+template <bool POINT>
 __global__ __launch_bounds__(HF_BLOCK) void hf_direct_kernel(size_t n, uint32_t spp, hf_f3ptr sn, hf_f3ptr dd,
-                                                            const float *__restrict__ t, hf_lights_dev L,
+                                                            const float *__restrict__ t, hf_f3ptr pp, hf_lights_dev L,
                                                             float *__restrict__ image) {
     const size_t i = (size_t) blockIdx.x * HF_BLOCK + threadIdx.x;
     const size_t npix = n / spp;
@@ -1584,9 +1587,19 @@ __global__ __launch_bounds__(HF_BLOCK) void hf_direct_kernel(size_t n, uint32_t 
     const bool pow2 = (spp & (spp - 1u)) == 0u;
     const uint32_t g = spp < 64u ? spp : 64u; // lanes per pixel within a wave (tree path)
     const float inv_spp = 1.0f / (float) spp;
+    v3 p = mk3(0.f, 0.f, 0.f);
+    if (POINT) p = mk3(pp.p[0][ii], pp.p[1][ii], pp.p[2][ii]);
     for (uint32_t k = 0; k < L.n; ++k) {
-        const float co = dot3(nn, mk3(L.l[k][0], L.l[k][1], L.l[k][2]));
-        float c = (lit && co > 0.f && (L.vis[k] ? L.vis[k][ii] != 0 : true)) ? L.w[k] * co : 0.f;
+        v3 l = mk3(L.l[k][0], L.l[k][1], L.l[k][2]);
+        float wk = L.w[k];
+        if (POINT) {
+            const v3 v = l - p;
+            const float ir = 1.0f / __builtin_sqrtf(dot3(v, v));
+            l = v * ir;
+            wk = wk * (ir * ir);
+        }
+        const float co = dot3(nn, l);
+        float c = (lit && co > 0.f && (L.vis[k] ? L.vis[k][ii] != 0 : true)) ? wk * co : 0.f;
         if (pow2) {
             // butterfly over the g = min(spp, 64) lanes of a pixel: DPP within rows of 16, cross-lane beyond
             if (g > 1u) c += HF_DPP_ADD(c, 0xB1);   // quad_perm [1,0,3,2]
@@ -1605,9 +1618,11 @@ __global__ __launch_bounds__(HF_BLOCK) void hf_direct_kernel(size_t n, uint32_t 
     }
 }
 
+// POINT: f = w (n.v) |v|^-3 with v = pos - p:  df/dn = w |v|^-2 l,  df/dp = w |v|^-3 (3 (n.l) l - n)
+template <bool POINT>
 __global__ __launch_bounds__(HF_BLOCK) void hf_direct_adjoint_kernel(size_t n, uint32_t spp, hf_f3ptr sn, hf_f3ptr dd,
-                                                                    const float *__restrict__ t, hf_lights_dev L,
-                                                                    const float *__restrict__ gimg, hf_f3out gn) {
+                                                                    const float *__restrict__ t, hf_f3ptr pp, hf_lights_dev L,
+                                                                    const float *__restrict__ gimg, hf_f3out gn, hf_f3out gp) {
     const size_t i = (size_t) blockIdx.x * HF_BLOCK + threadIdx.x;
     if (i >= n) return;
     const size_t npix = n / spp, pix = i / spp;
@@ -1615,36 +1630,66 @@ __global__ __launch_bounds__(HF_BLOCK) void hf_direct_adjoint_kernel(size_t n, u
     const v3 d = mk3(dd.p[0][i], dd.p[1][i], dd.p[2][i]);
     const bool lit = (t[i] != __builtin_inff()) && (-dot3(nn, d) > 0.f);
     const float inv_spp = 1.0f / (float) spp;
-    v3 g = mk3(0.f, 0.f, 0.f);
+    v3 g = mk3(0.f, 0.f, 0.f), gq = mk3(0.f, 0.f, 0.f);
+    v3 p = mk3(0.f, 0.f, 0.f);
+    if (POINT) p = mk3(pp.p[0][i], pp.p[1][i], pp.p[2][i]);
     for (uint32_t k = 0; k < L.n; ++k) {
-        const v3 l = mk3(L.l[k][0], L.l[k][1], L.l[k][2]);
-        if (lit && dot3(nn, l) > 0.f && (L.vis[k] ? L.vis[k][i] != 0 : true)) {
-            const float w = (L.w[k] * inv_spp) * gimg[k * npix + pix];
+        v3 l = mk3(L.l[k][0], L.l[k][1], L.l[k][2]);
+        float ir = 1.f;
+        if (POINT) {
+            const v3 v = l - p;
+            ir = 1.0f / __builtin_sqrtf(dot3(v, v));
+            l = v * ir;
+        }
+        const float co = dot3(nn, l);
+        if (lit && co > 0.f && (L.vis[k] ? L.vis[k][i] != 0 : true)) {
+            float w = (L.w[k] * inv_spp) * gimg[k * npix + pix];
+            if (POINT) {
+                w = w * (ir * ir);
+                const float wp = w * ir, c3 = 3.f * co;
+                gq.x = __builtin_fmaf(wp, __builtin_fmaf(c3, l.x, -nn.x), gq.x);
+                gq.y = __builtin_fmaf(wp, __builtin_fmaf(c3, l.y, -nn.y), gq.y);
+                gq.z = __builtin_fmaf(wp, __builtin_fmaf(c3, l.z, -nn.z), gq.z);
+            }
             g.x = __builtin_fmaf(w, l.x, g.x); g.y = __builtin_fmaf(w, l.y, g.y); g.z = __builtin_fmaf(w, l.z, g.z);
         }
     }
     gn.p[0][i] = g.x; gn.p[1][i] = g.y; gn.p[2][i] = g.z;
+    if (POINT) { gp.p[0][i] = gq.x; gp.p[1][i] = gq.y; gp.p[2][i] = gq.z; }
 }
 
 void hf_launch_direct(size_t n, uint32_t spp, const float *const sh_n[3], const float *const d[3], const float *t,
-                      const hf_lights_dev &lights, float *image, hipStream_t stream) {
+                      const float *const p[3], const hf_lights_dev &lights, float *image, hipStream_t stream) {
     if (n == 0) return;
     const bool pow2 = (spp & (spp - 1u)) == 0u;
     if (!pow2 || spp > 64u) (void) hipMemsetAsync(image, 0, sizeof(float) * lights.n * (n / spp), stream); // atomic paths
-    hf_f3ptr sn = { { sh_n[0], sh_n[1], sh_n[2] } }, dd = { { d[0], d[1], d[2] } };
+    hf_f3ptr sn = { { sh_n[0], sh_n[1], sh_n[2] } }, dd = { { d[0], d[1], d[2] } }, pp = { { nullptr, nullptr, nullptr } };
     const size_t blocks = (n + HF_BLOCK - 1) / HF_BLOCK;
-    hipLaunchKernelGGL(hf_direct_kernel, dim3((unsigned) blocks), dim3(HF_BLOCK), 0, stream, n, spp, sn, dd, t, lights, image);
+    if (p) { // point lights
+        pp = { { p[0], p[1], p[2] } };
+        hipLaunchKernelGGL(hf_direct_kernel<true>, dim3((unsigned) blocks), dim3(HF_BLOCK), 0, stream, n, spp, sn, dd, t, pp, lights, image);
+    } else {
+        hipLaunchKernelGGL(hf_direct_kernel<false>, dim3((unsigned) blocks), dim3(HF_BLOCK), 0, stream, n, spp, sn, dd, t, pp, lights, image);
+    }
 }
 
 void hf_launch_direct_adjoint(size_t n, uint32_t spp, const float *const sh_n[3], const float *const d[3],
-                              const float *t, const hf_lights_dev &lights, const float *grad_image,
-                              float *const grad_sh_n[3], hipStream_t stream) {
+                              const float *t, const float *const p[3], const hf_lights_dev &lights,
+                              const float *grad_image, float *const grad_sh_n[3], float *const grad_p[3],
+                              hipStream_t stream) {
     if (n == 0) return;
-    hf_f3ptr sn = { { sh_n[0], sh_n[1], sh_n[2] } }, dd = { { d[0], d[1], d[2] } };
-    hf_f3out gn = { { grad_sh_n[0], grad_sh_n[1], grad_sh_n[2] } };
+    hf_f3ptr sn = { { sh_n[0], sh_n[1], sh_n[2] } }, dd = { { d[0], d[1], d[2] } }, pp = { { nullptr, nullptr, nullptr } };
+    hf_f3out gn = { { grad_sh_n[0], grad_sh_n[1], grad_sh_n[2] } }, gp = { { nullptr, nullptr, nullptr } };
     const size_t blocks = (n + HF_BLOCK - 1) / HF_BLOCK;
-    hipLaunchKernelGGL(hf_direct_adjoint_kernel, dim3((unsigned) blocks), dim3(HF_BLOCK), 0, stream, n, spp, sn, dd, t,
-                       lights, grad_image, gn);
+    if (p) {
+        pp = { { p[0], p[1], p[2] } };
+        gp = { { grad_p[0], grad_p[1], grad_p[2] } };
+        hipLaunchKernelGGL(hf_direct_adjoint_kernel<true>, dim3((unsigned) blocks), dim3(HF_BLOCK), 0, stream, n, spp, sn, dd, t,
+                           pp, lights, grad_image, gn, gp);
+    } else {
+        hipLaunchKernelGGL(hf_direct_adjoint_kernel<false>, dim3((unsigned) blocks), dim3(HF_BLOCK), 0, stream, n, spp, sn, dd, t,
+                           pp, lights, grad_image, gn, gp);
+    }
 }
 
 // ---- warped-area reparameterisation: per-sample kernels (helpers: above hf_adjoint_kernel) ----

@@ -30,11 +30,14 @@ struct hf_lights_dev {
     const uint8_t *vis[HF_MAX_LIGHTS];
     uint32_t n;
 };
+// p == nullptr: directional lights (lights.l = unit direction towards the light, lights.w = albedo/pi * irradiance);
+// p != nullptr: point lights (lights.l = position, lights.w = albedo/pi * intensity), grad_p is then written too
 void hf_launch_direct(size_t n, uint32_t spp, const float *const sh_n[3], const float *const d[3], const float *t,
-                      const hf_lights_dev &lights, float *image, hipStream_t stream);
+                      const float *const p[3], const hf_lights_dev &lights, float *image, hipStream_t stream);
 void hf_launch_direct_adjoint(size_t n, uint32_t spp, const float *const sh_n[3], const float *const d[3],
-                              const float *t, const hf_lights_dev &lights, const float *grad_image,
-                              float *const grad_sh_n[3], hipStream_t stream);
+                              const float *t, const float *const p[3], const hf_lights_dev &lights,
+                              const float *grad_image, float *const grad_sh_n[3], float *const grad_p[3],
+                              hipStream_t stream);
 struct hf_reparam_args {
     size_t n;
     const float *o[3], *d[3];

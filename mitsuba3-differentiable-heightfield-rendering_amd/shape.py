@@ -659,6 +659,56 @@ def direct_lighting(si, ray, lights, albedo=1.0, spp=1, vis=None):
     return _DirectLightingOp.apply(si.sh_frame.n, ray.d, si.t, lights, float(albedo), int(spp), vis)
 
 
+class _PointLightingOp(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, sh_n, p, d, t, lights, albedo, spp, vis):
+        n = sh_n.shape[1]
+        K = lights.shape[0]
+        sn, sn_p = _f3(sh_n)
+        pp, pp_p = _f3(p)
+        dd, dd_p = _f3(d)
+        tt = t.to(dtype=torch.float32).contiguous()
+        L = (_capi.hf_dir_light_t * K)()   # hf_point_light_t: the same packing (position, intensity)
+        lh = lights.detach().cpu().tolist()
+        for k in range(K):
+            L[k].to_light[0], L[k].to_light[1], L[k].to_light[2], L[k].irradiance = lh[k]
+        vis_p = None
+        if vis is not None:
+            vis = vis.to(dtype=torch.uint8).contiguous()
+            vis_p = (C.c_void_p * K)(*[vis[k].data_ptr() for k in range(K)])
+        image = torch.empty((K, n // spp), dtype=torch.float32, device=sh_n.device)
+        stream = torch.cuda.current_stream(sh_n.device).cuda_stream
+        check(_capi.lib().hf_point_lighting(n, spp, C.byref(sn_p), C.byref(dd_p), tt.data_ptr(), C.byref(pp_p), K, L,
+                                            albedo, vis_p, image.data_ptr(), stream))
+        ctx.save_for_backward(sn, pp, dd, tt)
+        ctx.misc = (L, K, albedo, spp, vis, vis_p)
+        return image
+
+    @staticmethod
+    def backward(ctx, grad_image):
+        sn, pp, dd, tt = ctx.saved_tensors
+        L, K, albedo, spp, vis, vis_p = ctx.misc
+        n = sn.shape[1]
+        _, sn_p = _f3(sn)
+        _, pp_p = _f3(pp)
+        _, dd_p = _f3(dd)
+        gi = grad_image.to(dtype=torch.float32).contiguous()
+        gn = torch.empty_like(sn); gp = torch.empty_like(pp)
+        gn_p = (C.c_void_p * 3)(gn[0].data_ptr(), gn[1].data_ptr(), gn[2].data_ptr())
+        gp_p = (C.c_void_p * 3)(gp[0].data_ptr(), gp[1].data_ptr(), gp[2].data_ptr())
+        stream = torch.cuda.current_stream(sn.device).cuda_stream
+        check(_capi.lib().hf_point_lighting_adjoint(n, spp, C.byref(sn_p), C.byref(dd_p), tt.data_ptr(), C.byref(pp_p), K,
+                                                    L, albedo, vis_p, gi.data_ptr(), C.byref(gn_p), C.byref(gp_p), stream))
+        return gn, gp, None, None, None, None, None, None
+
+
+def point_lighting(si, ray, lights, albedo=1.0, spp=1, vis=None):
+    """``direct_lighting`` under POINT lights (``hf_point_lighting``; src/emitters/point.cpp): ``lights`` is a [K, 4]
+    tensor of (position, radiant intensity).  Differentiable with respect to ``si.sh_frame.n`` and ``si.p``."""
+    lights = torch.as_tensor(lights, dtype=torch.float32)
+    return _PointLightingOp.apply(si.sh_frame.n, si.p, ray.d, si.t, lights, float(albedo), int(spp), vis)
+
+
 def _p3(x):
     return (C.c_void_p * 3)(x[0].data_ptr(), x[1].data_ptr(), x[2].data_ptr())
 

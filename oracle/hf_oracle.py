@@ -288,6 +288,49 @@ def direct_lighting_adjoint(sh_n, d, t, lights, grad_image, albedo=1.0, spp=1, v
     return g
 
 
+def point_lighting(sh_n, p, d, t, lights, albedo=1.0, spp=1, vis=None):
+    """direct_lighting under point lights (float64 restatement of include/hf.h hf_point_lighting): the emitter of
+    src/emitters/point.cpp:106-123 -- direction (position - p) / r, radiance intensity / r^2 -- with the same BSDF
+    term, masks and film.  lights: [K,4] = (position, intensity).  Returns image [K, n // spp]."""
+    sh_n = np.asarray(sh_n, np.float64); p = np.asarray(p, np.float64); d = np.asarray(d, np.float64)
+    t = np.asarray(t, np.float64)
+    lights = np.asarray(lights, np.float64).reshape(-1, 4)
+    n = sh_n.shape[1]
+    lit = np.isfinite(t) & (-(sh_n * d).sum(0) > 0)
+    out = np.zeros((lights.shape[0], n // spp))
+    for k, L in enumerate(lights):
+        v = L[:3, None] - p
+        r2 = (v * v).sum(0)
+        l = v / np.sqrt(r2)
+        co = (sh_n * l).sum(0)
+        c = np.where(lit & (co > 0), albedo / np.pi * L[3] / r2 * co, 0.0)
+        if vis is not None:
+            c = c * (np.asarray(vis[k]) != 0)
+        out[k] = c.reshape(-1, spp).mean(1)
+    return out
+
+
+def point_lighting_adjoint(sh_n, p, d, t, lights, grad_image, albedo=1.0, spp=1, vis=None):
+    """d(sum(image * grad_image)) / d(sh_n) and / d(p), float64, by the closed form f = w <n, v> |v|^-3, v = position - p:
+    df/dn = w v |v|^-3,  df/dp = w |v|^-3 (3 <n, l> l - n)."""
+    sh_n = np.asarray(sh_n, np.float64); p = np.asarray(p, np.float64); d = np.asarray(d, np.float64)
+    t = np.asarray(t, np.float64)
+    lights = np.asarray(lights, np.float64).reshape(-1, 4)
+    lit = np.isfinite(t) & (-(sh_n * d).sum(0) > 0)
+    gn = np.zeros_like(sh_n); gp = np.zeros_like(p)
+    for k, L in enumerate(lights):
+        v = L[:3, None] - p
+        r = np.sqrt((v * v).sum(0))
+        l = v / r
+        co = (sh_n * l).sum(0)
+        w = np.where(lit & (co > 0), albedo / np.pi * L[3] / spp, 0.0) * np.repeat(np.asarray(grad_image, np.float64)[k], spp)
+        if vis is not None:
+            w = w * (np.asarray(vis[k]) != 0)
+        gn += (w / r ** 2)[None, :] * l
+        gp += (w / r ** 3)[None, :] * (3.0 * co[None, :] * l - sh_n)
+    return gn, gp
+
+
 # ---------------------------------------------------------------------------------------------------
 # Warped-area reparameterisation of rays for a scene that is this one shape: float64 restatement of
 # src/python/python/ad/reparam.py:10-123 (_sample_warp_field) and :151-333 (forward / backward of
