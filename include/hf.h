@@ -270,6 +270,21 @@ int hf_point_lighting_adjoint(size_t n, uint32_t spp, const float *const sh_n[3]
                               const float *grad_image, float *const grad_sh_n[3], float *const grad_p[3],
                               hf_stream_t stream);
 
+/* Film with a Gaussian reconstruction filter (the reference's default rfilter, src/rfilters/gaussian.cpp:48-101:
+ * w(x) = max(0, exp(-x^2 / (2 stddev^2)) - exp(-r^2 / (2 stddev^2))), r = 4 stddev), splatted as ImageBlock::put does
+ * (src/render/imageblock.cpp:258-330): sample i at film position (pos_x[i], pos_y[i]) (pixel units; pixel (x, y)
+ * covers [x, x+1) x [y, y+1)) adds w(x - (pos_x - 0.5)) w(y - (pos_y - 0.5)) * values[c][i] to image[c][y*width + x]
+ * and the weight alone to weight[y*width + x] for every pixel within r; image and weight are ACCUMULATED (zero them
+ * first), the film is image / weight (HDRFilm::develop).  values: `channels` (<= HF_MAX_LIGHTS) device arrays of n
+ * floats -- e.g. the rows of hf_direct_lighting(..., spp = 1, ...), which are the per-sample values.  0 < stddev <= 1.
+ * The adjoint gathers: grad_values[c][i] = sum_pixels w * grad_image[c][pixel], grad_image = dL/d(accumulated image)
+ * (for a loss on the normalised film: dL/d(film) / weight); the weights do not depend on the samples' values. */
+int hf_film_splat(size_t n, uint32_t channels, const float *const *values, const float *pos_x, const float *pos_y,
+                  uint32_t width, uint32_t height, float stddev, float *image, float *weight, hf_stream_t stream);
+int hf_film_splat_adjoint(size_t n, uint32_t channels, const float *pos_x, const float *pos_y, uint32_t width,
+                          uint32_t height, float stddev, const float *grad_image, float *const *grad_values,
+                          hf_stream_t stream);
+
 /* ---- next row: warped-area reparameterisation of rays ---------- */
 
 /* The auxiliary-ray machinery of mitsuba.ad.reparameterize_ray (src/python/python/ad/reparam.py:10-123,

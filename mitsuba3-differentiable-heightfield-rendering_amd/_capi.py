@@ -75,6 +75,10 @@ SYMBOLS = {
     "hf_point_lighting_adjoint": (C.c_int, [C.c_size_t, C.c_uint32, C.POINTER(_fp * 3), C.POINTER(_fp * 3), _fp,
                                             C.POINTER(_fp * 3), C.c_uint32, C.POINTER(hf_dir_light_t), C.c_float,
                                             C.POINTER(_fp), _fp, C.POINTER(_fp * 3), C.POINTER(_fp * 3), C.c_void_p]),
+    "hf_film_splat": (C.c_int, [C.c_size_t, C.c_uint32, C.POINTER(_fp), _fp, _fp, C.c_uint32, C.c_uint32, C.c_float, _fp, _fp,
+                                C.c_void_p]),
+    "hf_film_splat_adjoint": (C.c_int, [C.c_size_t, C.c_uint32, _fp, _fp, C.c_uint32, C.c_uint32, C.c_float, _fp,
+                                        C.POINTER(_fp), C.c_void_p]),
     "hf_reparam_aux_rays": (C.c_int, [C.c_size_t, C.POINTER(_fp * 3), C.POINTER(_fp * 3), _fp, C.c_uint32, C.c_float,
                                       C.c_int, C.c_uint32, C.POINTER(_fp * 3), _fp, C.c_void_p]),
     "hf_reparam_weights": (C.c_int, [C.c_int, C.c_size_t, C.POINTER(_fp * 3), C.POINTER(_fp * 3), _fp, C.c_uint32,

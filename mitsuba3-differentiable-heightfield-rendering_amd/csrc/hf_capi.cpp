@@ -525,6 +525,56 @@ extern "C" int hf_point_lighting_adjoint(size_t n, uint32_t spp, const float *co
     return HF_OK;
 }
 
+// ---- Gaussian reconstruction filter (film) ------------------------------------------------------
+static int splat_args(const char *who, size_t n, uint32_t channels, const float *pos_x, const float *pos_y,
+                      uint32_t width, uint32_t height, float stddev, hf_splat_args &a) {
+    if (!pos_x || !pos_y) return fail(HF_EINVAL, "%s: NULL film positions", who);
+    if (channels == 0 || channels > HF_MAX_LIGHTS) return fail(HF_EINVAL, "%s: 1..%d channels (got %u)", who, HF_MAX_LIGHTS, channels);
+    if (width == 0 || height == 0 || (size_t) width * height >= ((size_t) 1 << 31)) return fail(HF_EINVAL, "%s: bad film size", who);
+    if (!(stddev > 0.f) || stddev > 1.f) return fail(HF_EINVAL, "%s: stddev must be in (0, 1] pixels", who);
+    if (n >= ((size_t) 1 << 32)) return fail(HF_EINVAL, "%s: more than 2^32 samples", who);
+    a = {};
+    a.n = n; a.channels = channels; a.width = width; a.height = height; a.pos_x = pos_x; a.pos_y = pos_y;
+    a.radius = 4.f * stddev;                               // gaussian.cpp:52-53
+    a.alpha = -1.f / (2.f * stddev * stddev);              // gaussian.cpp:97-99
+    a.bias = expf(a.alpha * a.radius * a.radius);
+    return HF_OK;
+}
+
+extern "C" int hf_film_splat(size_t n, uint32_t channels, const float *const *values, const float *pos_x,
+                             const float *pos_y, uint32_t width, uint32_t height, float stddev, float *image,
+                             float *weight, hf_stream_t stream) {
+    hf_splat_args a;
+    const int rc = splat_args("hf_film_splat", n, channels, pos_x, pos_y, width, height, stddev, a);
+    if (rc != HF_OK) return rc;
+    if (!values || !image || !weight) return fail(HF_EINVAL, "hf_film_splat: NULL argument");
+    for (uint32_t k = 0; k < channels; ++k) {
+        if (!values[k]) return fail(HF_EINVAL, "hf_film_splat: NULL channel array");
+        a.values[k] = values[k];
+    }
+    a.image = image; a.weight = weight;
+    hf_launch_film_splat(a, false, (hipStream_t) stream);
+    HF_HIP(hipGetLastError());
+    return HF_OK;
+}
+
+extern "C" int hf_film_splat_adjoint(size_t n, uint32_t channels, const float *pos_x, const float *pos_y,
+                                     uint32_t width, uint32_t height, float stddev, const float *grad_image,
+                                     float *const *grad_values, hf_stream_t stream) {
+    hf_splat_args a;
+    const int rc = splat_args("hf_film_splat_adjoint", n, channels, pos_x, pos_y, width, height, stddev, a);
+    if (rc != HF_OK) return rc;
+    if (!grad_image || !grad_values) return fail(HF_EINVAL, "hf_film_splat_adjoint: NULL argument");
+    for (uint32_t k = 0; k < channels; ++k) {
+        if (!grad_values[k]) return fail(HF_EINVAL, "hf_film_splat_adjoint: NULL channel array");
+        a.grad_values[k] = grad_values[k];
+    }
+    a.grad_image = grad_image;
+    hf_launch_film_splat(a, true, (hipStream_t) stream);
+    HF_HIP(hipGetLastError());
+    return HF_OK;
+}
+
 // ---- warped-area reparameterisation --------------------------------------------
 
 extern "C" int hf_reparam_aux_rays(size_t n, const float *const o[3], const float *const d[3], const uint8_t *active,

@@ -1658,6 +1658,63 @@ __global__ __launch_bounds__(HF_BLOCK) void hf_direct_adjoint_kernel(size_t n, u
     if (POINT) { gp.p[0][i] = gq.x; gp.p[1][i] = gq.y; gp.p[2][i] = gq.z; }
 }
 
+// ---------------------------------------------------------------------------------
+// Gaussian reconstruction filter, splatted the way ImageBlock::put does (src/render/imageblock.cpp:258-330 with
+// src/rfilters/gaussian.cpp:48-101): a sample at film position pos adds  w_x(px) w_y(py) value  to every pixel
+// whose index lies in [ceil(pos - 0.5 - r), floor(pos - 0.5 + r)] (clamped to the film), with the windowed Gaussian
+// w(x) = max(0, exp(-x^2 / (2 stddev^2)) - exp(-r^2 / (2 stddev^2))), r = 4 stddev, x = pixel index - (pos - 0.5);
+// the accumulated weight goes to its own plane and the film divides by it.
+// ---------------------------------------------------------------------------------
+
+template <bool ADJOINT>
+__global__ __launch_bounds__(HF_BLOCK) void hf_film_splat_kernel(hf_splat_args a) {
+    const size_t i = (size_t) blockIdx.x * HF_BLOCK + threadIdx.x;
+    if (i >= a.n) return;
+    const float fx = a.pos_x[i] - 0.5f, fy = a.pos_y[i] - 0.5f;
+    const int x0 = max((int) ceilf(fx - a.radius), 0), x1 = min((int) floorf(fx + a.radius), (int) a.width - 1);
+    const int y0 = max((int) ceilf(fy - a.radius), 0), y1 = min((int) floorf(fy + a.radius), (int) a.height - 1);
+    float acc[HF_MAX_LIGHTS];
+    float val[HF_MAX_LIGHTS];
+#pragma unroll
+    for (uint32_t k = 0; k < HF_MAX_LIGHTS; ++k) {
+        acc[k] = 0.f;
+        val[k] = (!ADJOINT && k < a.channels) ? a.values[k][i] : 0.f;
+    }
+    const size_t plane = (size_t) a.width * a.height;
+    for (int y = y0; y <= y1; ++y) {
+        const float dy = (float) y - fy;
+        const float wy = fmaxf(expf(a.alpha * (dy * dy)) - a.bias, 0.f);
+        for (int x = x0; x <= x1; ++x) {
+            const float dx = (float) x - fx;
+            const float w = fmaxf(expf(a.alpha * (dx * dx)) - a.bias, 0.f) * wy;
+            if (w == 0.f) continue;
+            const size_t pix = (size_t) y * a.width + x;
+            if (ADJOINT) {
+#pragma unroll
+                for (uint32_t k = 0; k < HF_MAX_LIGHTS; ++k)
+                    if (k < a.channels) acc[k] = __builtin_fmaf(w, a.grad_image[k * plane + pix], acc[k]);
+            } else {
+                atomicAdd(a.weight + pix, w);
+#pragma unroll
+                for (uint32_t k = 0; k < HF_MAX_LIGHTS; ++k)
+                    if (k < a.channels) atomicAdd(a.image + k * plane + pix, w * val[k]);
+            }
+        }
+    }
+    if (ADJOINT) {
+#pragma unroll
+        for (uint32_t k = 0; k < HF_MAX_LIGHTS; ++k)
+            if (k < a.channels) a.grad_values[k][i] = acc[k];
+    }
+}
+
+void hf_launch_film_splat(const hf_splat_args &a, bool adjoint, hipStream_t stream) {
+    if (a.n == 0) return;
+    const dim3 grid((unsigned) ((a.n + HF_BLOCK - 1) / HF_BLOCK)), block(HF_BLOCK);
+    if (adjoint) hipLaunchKernelGGL(hf_film_splat_kernel<true>, grid, block, 0, stream, a);
+    else         hipLaunchKernelGGL(hf_film_splat_kernel<false>, grid, block, 0, stream, a);
+}
+
 void hf_launch_direct(size_t n, uint32_t spp, const float *const sh_n[3], const float *const d[3], const float *t,
                       const float *const p[3], const hf_lights_dev &lights, float *image, hipStream_t stream) {
     if (n == 0) return;

@@ -38,6 +38,17 @@ void hf_launch_direct_adjoint(size_t n, uint32_t spp, const float *const sh_n[3]
                               const float *t, const float *const p[3], const hf_lights_dev &lights,
                               const float *grad_image, float *const grad_sh_n[3], float *const grad_p[3],
                               hipStream_t stream);
+struct hf_splat_args {
+    size_t n;
+    uint32_t channels, width, height;
+    float alpha, bias, radius; // -1 / (2 stddev^2), exp(alpha r^2), r
+    const float *pos_x, *pos_y;
+    const float *values[HF_MAX_LIGHTS];   // forward: per-channel sample values
+    float *image, *weight;                // forward: accumulated [channels][H*W], [H*W]
+    const float *grad_image;              // adjoint: dL/d(accumulated image) [channels][H*W]
+    float *grad_values[HF_MAX_LIGHTS];    // adjoint: per-channel, overwritten
+};
+void hf_launch_film_splat(const hf_splat_args &a, bool adjoint, hipStream_t stream);
 struct hf_reparam_args {
     size_t n;
     const float *o[3], *d[3];

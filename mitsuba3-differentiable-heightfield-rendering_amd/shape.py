@@ -709,6 +709,47 @@ def point_lighting(si, ray, lights, albedo=1.0, spp=1, vis=None):
     return _PointLightingOp.apply(si.sh_frame.n, si.p, ray.d, si.t, lights, float(albedo), int(spp), vis)
 
 
+class _FilmGaussianOp(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, values, pos, width, height, stddev):
+        K, n = values.shape
+        v = values.detach().to(dtype=torch.float32).contiguous()
+        ps = pos.detach().to(dtype=torch.float32).contiguous()
+        image = torch.zeros((K, height * width), dtype=torch.float32, device=v.device)
+        weight = torch.zeros(height * width, dtype=torch.float32, device=v.device)
+        vp = (C.c_void_p * K)(*[v[k].data_ptr() for k in range(K)])
+        stream = torch.cuda.current_stream(v.device).cuda_stream
+        check(_capi.lib().hf_film_splat(n, K, vp, ps[0].data_ptr(), ps[1].data_ptr(), width, height, stddev,
+                                        image.data_ptr(), weight.data_ptr(), stream))
+        ctx.save_for_backward(ps, weight)
+        ctx.misc = (K, n, width, height, stddev)
+        covered = weight > 0
+        return torch.where(covered[None], image / torch.where(covered, weight, torch.ones_like(weight))[None],
+                           torch.zeros_like(image))
+
+    @staticmethod
+    def backward(ctx, grad_film):
+        ps, weight = ctx.saved_tensors
+        K, n, width, height, stddev = ctx.misc
+        covered = weight > 0
+        ga = torch.where(covered[None], grad_film.to(torch.float32) / torch.where(covered, weight, torch.ones_like(weight))[None],
+                         torch.zeros_like(grad_film, dtype=torch.float32)).contiguous()
+        gv = torch.empty((K, n), dtype=torch.float32, device=ps.device)
+        gp = (C.c_void_p * K)(*[gv[k].data_ptr() for k in range(K)])
+        stream = torch.cuda.current_stream(ps.device).cuda_stream
+        check(_capi.lib().hf_film_splat_adjoint(n, K, ps[0].data_ptr(), ps[1].data_ptr(), width, height, stddev,
+                                                ga.data_ptr(), gp, stream))
+        return gv, None, None, None, None
+
+
+def film_gaussian(values, pos, width, height, stddev=0.5):
+    """Film with the reference's default reconstruction filter (Gaussian, stddev 0.5 pixel; ``hf_film_splat``;
+    src/rfilters/gaussian.cpp, src/render/imageblock.cpp:258-330): ``values`` [K, n] per-sample values (e.g.
+    ``direct_lighting(..., spp=1)``), ``pos`` [2, n] film positions in pixels (``workload.film_positions``).  Returns the
+    normalised film [K, height * width] (accumulated value / accumulated weight); differentiable w.r.t. ``values``."""
+    return _FilmGaussianOp.apply(values, pos, int(width), int(height), float(stddev))
+
+
 def _p3(x):
     return (C.c_void_p * 3)(x[0].data_ptr(), x[1].data_ptr(), x[2].data_ptr())
 

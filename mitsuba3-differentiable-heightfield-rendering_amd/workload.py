@@ -111,6 +111,24 @@ def ortho_rays(film_w, film_h, spp, device, start=0, count=None, seed=0,
     return out
 
 
+def film_positions(film_w, film_h, spp, device, seed=0, pixels=None):
+    """Film positions (pixel units, [2, n] float32) of the samples of ortho_rays(film_w, film_h, spp, ..., seed, pixels):
+    pixel index + the same jitter -- what a reconstruction filter other than the box needs (hf_film_splat)."""
+    total = film_w * film_h * spp
+    idx = torch.arange(total, dtype=torch.int64, device=device)
+    if pixels is not None:
+        pixels = pixels.to(device=device, dtype=torch.int64)
+        loc = torch.arange(int(pixels.numel()) * spp, dtype=torch.int64, device=device)
+        idx = pixels[loc // spp] * spp + loc % spp
+    v0, v1 = tea32(torch.full_like(idx, seed), idx)
+    jx = (v0 >> 9).to(torch.float64) * (1.0 / (1 << 23))
+    jy = (v1 >> 9).to(torch.float64) * (1.0 / (1 << 23))
+    pix = idx // spp
+    py = pix // film_w
+    px = pix - py * film_w
+    return torch.stack([(px.to(torch.float64) + jx), (py.to(torch.float64) + jy)]).to(torch.float32)
+
+
 def secondary_rays(p, n, seed, light_dir=(0.3, 0.2, 0.9)):
     """Incoherent follow-up rays from hit points p [3,n] with normals n [3,n]:
     one cosine-hemisphere bounce and one shadow ray toward a directional light.

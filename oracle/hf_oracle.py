@@ -331,6 +331,54 @@ def point_lighting_adjoint(sh_n, p, d, t, lights, grad_image, albedo=1.0, spp=1,
     return gn, gp
 
 
+def _gauss_w(x, stddev):
+    """src/rfilters/gaussian.cpp:48-101 (the exponential form of its CUDA branch): windowed Gaussian, radius 4 stddev"""
+    alpha = -1.0 / (2.0 * stddev * stddev)
+    r = 4.0 * stddev
+    return np.maximum(np.exp(alpha * x * x) - np.exp(alpha * r * r), 0.0)
+
+
+def film_splat(values, pos, width, height, stddev=0.5):
+    """ImageBlock::put with a Gaussian reconstruction filter (src/render/imageblock.cpp:258-330), float64: returns
+    (accumulated image [K, H*W], accumulated weight [H*W]); the film is image / weight."""
+    values = np.asarray(values, np.float64); pos = np.asarray(pos, np.float64)
+    K, n = values.shape
+    img = np.zeros((K, height * width)); wgt = np.zeros(height * width)
+    r = 4.0 * stddev
+    for i in range(n):
+        fx, fy = pos[0, i] - 0.5, pos[1, i] - 0.5
+        x0, x1 = max(int(np.ceil(fx - r)), 0), min(int(np.floor(fx + r)), width - 1)
+        y0, y1 = max(int(np.ceil(fy - r)), 0), min(int(np.floor(fy + r)), height - 1)
+        if x0 > x1 or y0 > y1:
+            continue
+        wx = _gauss_w(np.arange(x0, x1 + 1) - fx, stddev); wy = _gauss_w(np.arange(y0, y1 + 1) - fy, stddev)
+        w = wy[:, None] * wx[None, :]
+        pix = (np.arange(y0, y1 + 1)[:, None] * width + np.arange(x0, x1 + 1)[None, :])
+        np.add.at(wgt, pix, w)
+        for k in range(K):
+            np.add.at(img[k], pix, w * values[k, i])
+    return img, wgt
+
+
+def film_splat_adjoint(pos, width, height, grad_image, stddev=0.5):
+    """d(sum(image * grad_image)) / d(values): grad_values[k, i] = sum_pixels w(i, pixel) grad_image[k, pixel]"""
+    pos = np.asarray(pos, np.float64); grad_image = np.asarray(grad_image, np.float64)
+    K = grad_image.shape[0]; n = pos.shape[1]
+    g = np.zeros((K, n))
+    r = 4.0 * stddev
+    for i in range(n):
+        fx, fy = pos[0, i] - 0.5, pos[1, i] - 0.5
+        x0, x1 = max(int(np.ceil(fx - r)), 0), min(int(np.floor(fx + r)), width - 1)
+        y0, y1 = max(int(np.ceil(fy - r)), 0), min(int(np.floor(fy + r)), height - 1)
+        if x0 > x1 or y0 > y1:
+            continue
+        wx = _gauss_w(np.arange(x0, x1 + 1) - fx, stddev); wy = _gauss_w(np.arange(y0, y1 + 1) - fy, stddev)
+        w = wy[:, None] * wx[None, :]
+        pix = (np.arange(y0, y1 + 1)[:, None] * width + np.arange(x0, x1 + 1)[None, :])
+        g[:, i] = (grad_image[:, pix] * w[None]).sum((1, 2))
+    return g
+
+
 # ---------------------------------------------------------------------------------------------------
 # Warped-area reparameterisation of rays for a scene that is this one shape: float64 restatement of
 # src/python/python/ad/reparam.py:10-123 (_sample_warp_field) and :151-333 (forward / backward of

@@ -180,3 +180,88 @@ def test_gpu_point_light_to_height_gradient_chain(hf, oracle):
     got = shape.heightfield.grad.cpu().numpy()
     assert np.linalg.norm(gh) > 0 and np.abs(gp).max() > 0
     assert np.linalg.norm(got - gh) <= 2e-5 * np.linalg.norm(gh)
+
+
+# ---- Gaussian reconstruction filter (src/rfilters/gaussian.cpp, ImageBlock::put) -------------------------------
+def test_oracle_gaussian_film_known_answers(oracle):
+    # one sample at the centre of pixel (2, 1) of a 5x4 film: symmetric weights, peak 1 - exp(-8) at the centre,
+    # exp(-2) - exp(-8) one pixel away (stddev 0.5: alpha = -2), zero from two pixels on (radius 2)
+    img, w = oracle.film_splat(np.array([[3.0]]), np.array([[2.5], [1.5]]), 5, 4)
+    W = w.reshape(4, 5)
+    assert np.isclose(W[1, 2], (1 - np.exp(-8.0)) ** 2)
+    assert np.isclose(W[1, 1], (np.exp(-2.0) - np.exp(-8.0)) * (1 - np.exp(-8.0))) and np.isclose(W[1, 1], W[1, 3]) and np.isclose(W[0, 2], W[2, 2])
+    assert W[1, 0] == 0 and W[3, 2] == 0 and W[1, 4] == 0
+    assert np.allclose(img[0][w > 0] / w[w > 0], 3.0)           # a constant signal is reproduced wherever the film is covered
+    # out-of-film samples contribute to the pixels they still reach, samples further than the radius to none
+    _, w2 = oracle.film_splat(np.array([[1.0, 1.0]]), np.array([[-1.0, -3.0], [1.5, 1.5]]), 5, 4)
+    assert w2.reshape(4, 5)[1, 0] > 0 and np.count_nonzero(w2) == 3
+
+
+def test_oracle_gaussian_film_adjoint_is_the_transpose(oracle):
+    rng = np.random.default_rng(8)
+    n, K, Wd, Hd = 200, 3, 9, 7
+    pos = np.stack([rng.uniform(-1, Wd + 1, n), rng.uniform(-1, Hd + 1, n)])
+    v = rng.normal(size=(K, n)); g = rng.normal(size=(K, Wd * Hd))
+    img, _ = oracle.film_splat(v, pos, Wd, Hd)
+    gv = oracle.film_splat_adjoint(pos, Wd, Hd, g)
+    assert np.isclose((img * g).sum(), (gv * v).sum(), rtol=1e-12)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("stddev", [0.5, 1.0, 0.3])
+def test_gpu_gaussian_film_matches_oracle(hf, oracle, stddev):
+    import torch
+    rng = np.random.default_rng(int(stddev * 10))
+    n, K, Wd, Hd = 6000, 3, 23, 17
+    pos = np.stack([rng.uniform(-1.5, Wd + 1.5, n), rng.uniform(-1.5, Hd + 1.5, n)]).astype(np.float32)
+    v = rng.normal(size=(K, n)).astype(np.float32)
+    img, w = oracle.film_splat(v, pos, Wd, Hd, stddev)
+    vt = torch.from_numpy(v).cuda().requires_grad_(True)
+    film = hf.film_gaussian(vt, torch.from_numpy(pos).cuda(), Wd, Hd, stddev)
+    ref = np.where(w > 0, img / np.where(w > 0, w, 1.0), 0.0)
+    assert np.allclose(film.detach().cpu().numpy(), ref, rtol=2e-4, atol=2e-5)
+    g = rng.normal(size=ref.shape).astype(np.float32)
+    (film * torch.from_numpy(g).cuda()).sum().backward()
+    ga = np.where(w > 0, g / np.where(w > 0, w, 1.0), 0.0)
+    gref = oracle.film_splat_adjoint(pos, Wd, Hd, ga, stddev)
+    assert np.allclose(vt.grad.cpu().numpy(), gref, rtol=2e-4, atol=2e-5)
+
+
+@pytest.mark.gpu
+def test_gpu_gaussian_film_render_chain(hf, oracle):
+    """per-sample shading (hf_direct_lighting with spp = 1) -> Gaussian film -> loss -> backward to dL/dheight, against
+    the oracle's chain; and the film of a constant signal is that constant."""
+    import torch
+    rng = np.random.default_rng(14)
+    h = (0.5 + 0.2 * rng.uniform(-1, 1, (33, 33))).astype(np.float32)
+    shape = hf.Heightfield(heightfield=torch.from_numpy(h).cuda(), max_height=0.5)
+    shape.heightfield.requires_grad_(True)
+    Wd = Hd = 24; spp = 4
+    kw = dict(origin=(0.6, 0.35, 2.0), target=(0.0, 0.0, 0.25), scale=(0.9, 0.9, 1.0))
+    rays = hf.workload.ortho_rays(Wd, Hd, spp, "cuda", seed=3, **kw)
+    pos = hf.workload.film_positions(Wd, Hd, spp, "cuda", seed=3)
+    assert float(pos[0].min()) >= 0 and float(pos[0].max()) <= Wd and pos.shape == (2, Wd * Hd * spp)
+    ray = hf.Ray3f(rays[0:3], rays[3:6], rays[6])
+    si = shape.ray_intersect(ray, hf.RayFlags.All)
+    L = torch.from_numpy(LIGHTS.astype(np.float32))
+    samples = hf.direct_lighting(si, ray, L, albedo=0.8, spp=1)                 # [K, n]: one "pixel" per sample
+    film = hf.film_gaussian(samples, pos, Wd, Hd)
+    gi = torch.from_numpy(rng.normal(size=tuple(film.shape)).astype(np.float32)).cuda()
+    (film * gi).sum().backward()
+    const = hf.film_gaussian(torch.full((1, Wd * Hd * spp), 2.5, device="cuda"), pos, Wd, Hd)
+    assert torch.allclose(const, torch.full_like(const, 2.5), rtol=1e-5)
+    # oracle chain
+    r = rays.cpu().numpy(); p = pos.cpu().numpy()
+    f = oracle.OracleField(h, max_height=0.5)
+    t, u, v, prim = f.ray_intersect_preliminary(r)
+    rec = f.compute_surface_interaction(r, t, u, v, prim, oracle.RAY_ALL)
+    s = oracle.direct_lighting(rec["sh_n"], r[3:6], rec["t"], LIGHTS.astype(np.float32), albedo=0.8, spp=1)
+    img, w = oracle.film_splat(s, p, Wd, Hd)
+    ref = np.where(w > 0, img / np.where(w > 0, w, 1.0), 0.0)
+    assert np.allclose(film.detach().cpu().numpy(), ref, rtol=2e-4, atol=2e-5)
+    ga = np.where(w > 0, gi.cpu().numpy() / np.where(w > 0, w, 1.0), 0.0)
+    gs = oracle.film_splat_adjoint(p, Wd, Hd, ga)
+    gn = oracle.direct_lighting_adjoint(rec["sh_n"], r[3:6], rec["t"], LIGHTS.astype(np.float32), gs, albedo=0.8, spp=1)
+    gh = f.adjoint(r, t, u, v, prim, {"sh_n": gn.astype(np.float32)}, oracle.RAY_ALL)
+    got = shape.heightfield.grad.cpu().numpy()
+    assert np.linalg.norm(gh) > 0 and np.linalg.norm(got - gh) <= 1e-4 * np.linalg.norm(gh)
