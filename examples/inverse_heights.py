@@ -48,11 +48,17 @@ def render_reparameterized(shape, ray, lights, spp, aux=8, kappa=2e4, seed=0):
     return images, depth, valid
 
 
-def render(shape, ray, lights, spp, shadows=False, silhouette=False, aux=8, kappa=2e4):
+def render(shape, ray, lights, spp, shadows=False, silhouette=False, aux=8, kappa=2e4, film=None):
+    """film: None = box filter (pixel = mean of its samples, inside hf_direct_lighting); (positions [2, n], width,
+    height) = the reference's default Gaussian reconstruction filter (hf_film_splat) on the per-sample values"""
     if silhouette:
         return render_reparameterized(shape, ray, lights, spp, aux, kappa)
     si = shape.ray_intersect(ray, hf_amd.RayFlags.All)
     valid = si.is_valid()
+    if film is not None:
+        samples = hf_amd.direct_lighting(si, ray, lights, albedo=1.0, spp=1)          # [K, n]
+        images = hf_amd.film_gaussian(samples, film[0], film[1], film[2])
+        return images, torch.where(valid, si.t, torch.zeros_like(si.t)), valid
     vis = None
     if shadows:  # detached visibility of each light: one any-hit launch per light (scene.cpp:290-293)
         with torch.no_grad():
@@ -71,7 +77,7 @@ def centred_error(h, target):
 
 
 def run(grid=128, film=256, spp=1, steps=100, lr=0.02, device="cuda", verbose=True, seed=0, shadows=False,
-        depth_weight=0.0, silhouette=False, aux=8, kappa=2e4):
+        depth_weight=0.0, silhouette=False, aux=8, kappa=2e4, gaussian_film=False):
     dev = torch.device(device)
     lights = torch.cat([LIGHTS / LIGHTS.norm(dim=1, keepdim=True), torch.full((len(LIGHTS), 1), math.pi)], 1)  # E = pi
     target_h = hf_amd.workload.sine_heights(grid, grid, device=dev)
@@ -79,9 +85,10 @@ def run(grid=128, film=256, spp=1, steps=100, lr=0.02, device="cuda", verbose=Tr
     rays = hf_amd.workload.ortho_rays(film, film, spp, dev, seed=seed, origin=(0.6, 0.35, 2.0),
                                       target=(0.0, 0.0, 0.25), scale=(0.95, 0.95, 1.0))
     ray = hf_amd.Ray3f(rays[0:3], rays[3:6], rays[6])
+    flm = (hf_amd.workload.film_positions(film, film, spp, dev, seed=seed), film, film) if gaussian_film else None
     target = hf_amd.Heightfield(heightfield=target_h, max_height=0.5)
     with torch.no_grad():
-        tgt_img, tgt_depth, tgt_valid = render(target, ray, lights, spp, shadows)
+        tgt_img, tgt_depth, tgt_valid = render(target, ray, lights, spp, shadows, film=flm)
     shape = hf_amd.Heightfield(heightfield=torch.full_like(target_h, 0.5), max_height=0.5)
     shape.heightfield.requires_grad_(True)
     opt = hf_amd.Adam(shape, lr=lr)                       # hf_adam_step: optimizers.py:263-300 + params.update
@@ -89,7 +96,7 @@ def run(grid=128, film=256, spp=1, steps=100, lr=0.02, device="cuda", verbose=Tr
     t0 = time.perf_counter()
     for it in range(steps):
         opt.zero_grad()
-        images, depth, valid = render(shape, ray, lights, spp, shadows, silhouette, aux, kappa)
+        images, depth, valid = render(shape, ray, lights, spp, shadows, silhouette, aux, kappa, film=flm)
         both = valid & tgt_valid
         loss = ((images - tgt_img) ** 2).sum(0).mean()          # the multi-light renders only (configs[4])
         if depth_weight > 0:                                    # optional extra supervision, off by default
@@ -127,6 +134,7 @@ if __name__ == "__main__":
     ap.add_argument("--depth-weight", type=float, default=0.0, help="weight of an extra depth term (0 = images only)")
     ap.add_argument("--silhouette", action="store_true", help="reparameterised primary rays (discontinuity term)")
     ap.add_argument("--aux", type=int, default=8, help="auxiliary rays per primary ray of --silhouette")
+    ap.add_argument("--gaussian-film", action="store_true", help="Gaussian reconstruction filter instead of the box film")
     a = ap.parse_args()
     run(a.grid, a.film, a.spp, a.steps, a.lr, shadows=a.shadows, depth_weight=a.depth_weight, silhouette=a.silhouette,
-        aux=a.aux)
+        aux=a.aux, gaussian_film=a.gaussian_film)

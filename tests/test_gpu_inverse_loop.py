@@ -78,6 +78,13 @@ def test_inverse_loop_with_silhouette_term(hf):
     assert hist[-1] < 0.6 * hist[0], (hist[0], hist[-1])
 
 
+def test_inverse_loop_with_gaussian_film(hf):
+    """the loop with the reference's default reconstruction filter (hf_film_splat on the per-sample values)"""
+    import inverse_heights
+    hist, err, wall = inverse_heights.run(grid=64, film=64, spp=4, steps=25, lr=0.03, verbose=False, gaussian_film=True)
+    assert hist[-1] < 0.5 * hist[0], (hist[0], hist[-1])
+
+
 def test_cxx_host_drives_the_abi_without_python(hf):
     """examples/host_loop.cpp: trace -> shade -> adjoints -> Adam through include/hf.h from plain C++
     (built by __graft_entry__.build()); exit code 0 = the loss dropped 5x."""
