@@ -101,6 +101,37 @@ def test_config2_adjoint_vs_oracle_and_float64_finite_differences(hf, oracle):
     assert np.abs(blk_g - blk_f).max() <= 1e-2 * np.abs(blk_f).max()
 
 
+def test_config2_reparameterized_gradient_at_full_size(hf, oracle):
+    """configs[2] names prb_reparam: the backward of reparameterize_ray (4 auxiliary rays, kappa 1e5, exponent 3 --
+    the reference's defaults, reparam.py:336-340) on the 2048^2 grid with all 4.19 M primary rays of a 512^2 @16spp
+    sensor, hf_reparam_trace x 4 + hf_reparam_backward, against the oracle's float64 restatement."""
+    shape, h, rays, ray = _setup(hf, 2048, 512, 16)
+    shape.heightfield.requires_grad_(True)
+    n = rays.shape[1]
+    g = torch.Generator(device="cpu").manual_seed(5)
+    gd = torch.randn((3, n), generator=g).cuda(); gdiv = torch.randn(n, generator=g).cuda()
+    dirn, det = hf.reparameterize_ray(shape, ray, num_rays=4, kappa=1e5, exponent=3.0, seed=9)
+    ((dirn * gd).sum() + (det * gdiv).sum()).backward()
+    got = shape.heightfield.grad.double().cpu().numpy()
+    f = oracle.OracleField(h.cpu().numpy(), max_height=0.5)
+    r = rays.cpu().numpy()
+    ref = oracle.reparam_backward(f, r[0:3], r[3:6], gd.cpu().numpy(), gdiv.cpu().numpy(), num_rays=4, kappa=1e5,
+                                  exponent=3.0, seed=9, nthreads=16)
+    nrm = np.linalg.norm(ref)
+    assert nrm > 0 and np.count_nonzero(ref) > 100000
+    # The harmonic weights (1 / (D - 1 + B))^3 span many orders of magnitude: a handful of auxiliary hits next to a
+    # silhouette (B -> 0) carry most of the gradient's norm, and their float32 weights (like the reference's Float)
+    # differ from the float64 oracle's in the fourth digit.  So: a loose bound on the whole texture, a tight one on
+    # everything but the 100 texels with the largest difference.
+    diff = np.abs(got - ref).ravel()
+    rel = np.linalg.norm(diff) / nrm
+    rest = np.sort(diff)[:-100]
+    rel_rest = np.linalg.norm(rest) / nrm
+    print("reparam full size: rel", rel, "without the 100 worst texels", rel_rest)
+    assert rel <= 2e-3, rel
+    assert rel_rest <= 1e-4, rel_rest
+
+
 def test_config3_properties_at_full_size(hf, oracle):
     N, film, spp = 4096, 1024, 64
     shape, h, rays, ray = _setup(hf, N, film, spp)
