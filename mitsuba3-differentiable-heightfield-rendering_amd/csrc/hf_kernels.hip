@@ -115,6 +115,65 @@ __global__ __launch_bounds__(HF_BLOCK) void hf_shear_slope_kernel(int sh, float4
     rec[0].w = __builtin_fabsf(pl.x) + __builtin_fabsf(pl.y) + rmax;
 }
 
+// Level 1 (three quarters of all records, 201 MB at N = 4096): one thread per node -- the 3x3 vertex window is read
+// once, the four children are the cells themselves, the slope factor is computed in the same pass and the record is
+// written as three 16-byte stores.  Same arithmetic as hf_shear_kernel + hf_shear_slope_kernel with L = 1.
+// The same window also gives the node's entry of the min/max pyramid (hf_mip_level1_kernel's value: clamping only
+// repeats vertices of existing cells), written when mip1 is not null.
+__global__ __launch_bounds__(HF_BLOCK) void hf_shear_level1_kernel(const float *__restrict__ h, int W, int H, float s,
+                                                                  int sh, float4 *__restrict__ out,
+                                                                  float2 *__restrict__ mip1) {
+    const int node = blockIdx.x * HF_BLOCK + threadIdx.x;
+    if (node >= (1 << (2 * sh))) return;
+    const int iy = node >> sh, ix = node & ((1 << sh) - 1);
+    const int x0 = 2 * ix, y0 = 2 * iy;
+    float z[3][3]; // vertex window, clamped to the grid (clamped entries are only used where the kernel above clamps too)
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            z[i][j] = h[(size_t) min(y0 + i, H - 1) * W + min(x0 + j, W - 1)] * s;
+    if (mip1) {
+        float mn = __builtin_inff(), mx = -__builtin_inff();
+        if (y0 <= H - 2 && x0 <= W - 2) { // at least cell (x0, y0) exists
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) { mn = fminf(mn, z[i][j]); mx = fmaxf(mx, z[i][j]); }
+        }
+        mip1[node] = make_float2(mn, mx);
+    }
+    const float z00 = z[0][0], z10 = z[0][2], z01 = z[2][0], z11 = z[2][2];
+    const float inv = 0.5f / 2.f;
+    const float a = ((z10 - z00) + (z11 - z01)) * inv, b = ((z01 - z00) + (z11 - z10)) * inv;
+    const float c = 0.25f * ((z00 + z10) + (z01 + z11));
+    const float xc = (float) (x0 + 1), yc = (float) (y0 + 1);
+    const float eps = 1e-6f * (__builtin_fabsf(c) + (__builtin_fabsf(a) + __builtin_fabsf(b)) * 2.f);
+    float lo[4], hi[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int cj = x0 + (j & 1), ci = y0 + (j >> 1); // the child is cell (cj, ci)
+        lo[j] = __builtin_inff(); hi[j] = -__builtin_inff();
+        if (cj <= W - 2 && ci <= H - 2) {
+#pragma unroll
+            for (int di = 0; di < 2; ++di) {
+                const float row = __builtin_fmaf(b, (float) (ci + di) - yc, c);
+#pragma unroll
+                for (int dj = 0; dj < 2; ++dj) {
+                    const float w = z[(j >> 1) + di][(j & 1) + dj] - __builtin_fmaf(a, (float) (cj + dj) - xc, row);
+                    lo[j] = fminf(lo[j], w); hi[j] = fmaxf(hi[j], w);
+                }
+            }
+            lo[j] -= eps; hi[j] += eps;
+        }
+    }
+    const float rmax = fmaxf(fmaxf(fmaxf(hi[0] - lo[0], hi[1] - lo[1]), fmaxf(hi[2] - lo[2], hi[3] - lo[3])), 0.f); // absent: -inf
+    float4 *rec = out + (size_t) node * 3;
+    rec[0] = make_float4(a, b, c, __builtin_fabsf(a) + __builtin_fabsf(b) + rmax);
+    rec[1] = make_float4(lo[0], hi[0], lo[1], hi[1]);
+    rec[2] = make_float4(lo[2], hi[2], lo[3], hi[3]);
+}
+
 // Levels above HF_SHEAR_TOP keep plain min/max boxes, stored in the same record form with the zero plane
 // (a = b = c = 0, slope factor 0: w = z, and shear_line leaves the ray's z line untouched bit for bit), so that
 // the per-lane walk reads every inner node through ONE code path -- three 16-byte loads from one address.
@@ -137,6 +196,11 @@ void hf_launch_build_mips(const hf_dev_field &f, float2 *mip, float4 *shear, hip
     for (int L = 1; L <= top && L <= HF_SHEAR_TOP; ++L) { // level 1: the children are the cells themselves
         const int k = top - L, n = 1 << (2 * k);
         float4 *recs = shear + (size_t) (hf_depth_off(k) - 1u) * 3;
+        if (L == 1) {
+            hipLaunchKernelGGL(hf_shear_level1_kernel, dim3((n + HF_BLOCK - 1) / HF_BLOCK), dim3(HF_BLOCK), 0, stream, f.h,
+                               f.W, f.H, f.s, k, recs, mip + hf_depth_off(k)); // + depth top-1 of the pyramid
+            continue;
+        }
         hipLaunchKernelGGL(hf_shear_kernel, dim3((4 * n + HF_BLOCK - 1) / HF_BLOCK), dim3(HF_BLOCK), 0, stream, f.h, f.W,
                            f.H, f.s, L, k, recs);
         hipLaunchKernelGGL(hf_shear_slope_kernel, dim3((n + HF_BLOCK - 1) / HF_BLOCK), dim3(HF_BLOCK), 0, stream, k, recs);
@@ -144,10 +208,11 @@ void hf_launch_build_mips(const hf_dev_field &f, float2 *mip, float4 *shear, hip
     (void) hipMemsetAsync(mip, 0, sizeof(float2), stream); // padding entry
     for (int k = top - 1; k >= 0; --k) {
         const int n = 1 << (2 * k), grid = (n + HF_BLOCK - 1) / HF_BLOCK;
-        if (k == top - 1)
+        if (k == top - 1) {
+            if (top >= 1 && HF_SHEAR_TOP >= 1) continue; // written by hf_shear_level1_kernel above
             hipLaunchKernelGGL(hf_mip_level1_kernel, dim3(grid), dim3(HF_BLOCK), 0, stream, f.h, f.W, f.H, f.s,
                                mip + hf_depth_off(k), k);
-        else
+        } else
             hipLaunchKernelGGL(hf_mip_reduce_kernel, dim3(grid), dim3(HF_BLOCK), 0, stream,
                                (const float2 *) (mip + hf_depth_off(k + 1)), mip + hf_depth_off(k), k);
     }
