@@ -191,6 +191,34 @@ __global__ __launch_bounds__(HF_BLOCK) void hf_shear_minmax_kernel(const float2 
     rec[2] = make_float4(d.x, d.y, e.x, e.y);
 }
 
+// The top of the pyramid in ONE launch: depths kmax..0 (at most 64x64 nodes each) by a single workgroup, level after
+// level -- the 2x2 reduce of hf_mip_reduce_kernel and, above HF_SHEAR_TOP, the record of hf_shear_minmax_kernel, both
+// from depth k+1, which the previous iteration (or the previous launch, for kmax) has completed.
+#define HF_MIP_TOP_DEPTH 6
+__global__ __launch_bounds__(1024) void hf_mip_top_kernel(float2 *__restrict__ mip, float4 *__restrict__ shear, int top,
+                                                         int kmax) {
+    for (int k = kmax; k >= 0; --k) {
+        const float2 *c0 = mip + hf_depth_off(k + 1);
+        float2 *o = mip + hf_depth_off(k);
+        const bool rec_level = (top - k) > HF_SHEAR_TOP;
+        float4 *recs = shear + (size_t) (hf_depth_off(k) - 1u) * 3;
+        for (int node = (int) threadIdx.x; node < (1 << (2 * k)); node += (int) blockDim.x) {
+            const int iy = node >> k, ix = node & ((1 << k) - 1);
+            const float2 *c = c0 + ((size_t) (2 * iy) << (k + 1)) + 2 * ix;
+            const float2 a = c[0], b = c[1], d = c[(size_t) 1 << (k + 1)], e = c[((size_t) 1 << (k + 1)) + 1];
+            o[node] = make_float2(fminf(fminf(a.x, b.x), fminf(d.x, e.x)), fmaxf(fmaxf(a.y, b.y), fmaxf(d.y, e.y)));
+            if (rec_level) {
+                float4 *rec = recs + (size_t) node * 3;
+                rec[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+                rec[1] = make_float4(a.x, a.y, b.x, b.y);
+                rec[2] = make_float4(d.x, d.y, e.x, e.y);
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
 void hf_launch_build_mips(const hf_dev_field &f, float2 *mip, float4 *shear, hipStream_t stream) {
     const int top = f.top;
     for (int L = 1; L <= top && L <= HF_SHEAR_TOP; ++L) { // level 1: the children are the cells themselves
@@ -206,7 +234,10 @@ void hf_launch_build_mips(const hf_dev_field &f, float2 *mip, float4 *shear, hip
         hipLaunchKernelGGL(hf_shear_slope_kernel, dim3((n + HF_BLOCK - 1) / HF_BLOCK), dim3(HF_BLOCK), 0, stream, k, recs);
     }
     (void) hipMemsetAsync(mip, 0, sizeof(float2), stream); // padding entry
-    for (int k = top - 1; k >= 0; --k) {
+    // depths <= ktop of the pyramid and their records come from one launch at the end (hf_mip_top_kernel); every level
+    // it covers must be a plain min/max level (the fitted-plane levels 1..HF_SHEAR_TOP are built from the heights)
+    const int ktop = max(min(HF_MIP_TOP_DEPTH, top - 1 - HF_SHEAR_TOP), -1); // -1: no such level (top <= HF_SHEAR_TOP)
+    for (int k = top - 1; k > ktop; --k) {
         const int n = 1 << (2 * k), grid = (n + HF_BLOCK - 1) / HF_BLOCK;
         if (k == top - 1) {
             if (top >= 1 && HF_SHEAR_TOP >= 1) continue; // written by hf_shear_level1_kernel above
@@ -218,9 +249,12 @@ void hf_launch_build_mips(const hf_dev_field &f, float2 *mip, float4 *shear, hip
     }
     for (int L = HF_SHEAR_TOP + 1; L <= top; ++L) { // after the pyramid: reads depth k+1 of it
         const int k = top - L, n = 1 << (2 * k);
+        if (k <= ktop) break; // the rest: hf_mip_top_kernel
         hipLaunchKernelGGL(hf_shear_minmax_kernel, dim3((n + HF_BLOCK - 1) / HF_BLOCK), dim3(HF_BLOCK), 0, stream,
                            (const float2 *) (mip + hf_depth_off(k + 1)), k, shear + (size_t) (hf_depth_off(k) - 1u) * 3);
     }
+    if (ktop >= 0)
+        hipLaunchKernelGGL(hf_mip_top_kernel, dim3(1), dim3(1024), 0, stream, mip, shear, top, ktop);
 }
 
 // ---------------------------------------------------------------------------------
