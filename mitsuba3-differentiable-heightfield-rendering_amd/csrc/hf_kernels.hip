@@ -98,26 +98,24 @@ __global__ __launch_bounds__(HF_BLOCK) void hf_shear_kernel(const float *__restr
         const float eps = 1e-6f * (__builtin_fabsf(c) + (__builtin_fabsf(a) + __builtin_fabsf(b)) * (float) size);
         lo -= eps; hi += eps;
     }
+    // fourth entry of the record (see below): slope of the plane + the largest child range, over the node's four
+    // threads (adjacent lanes; an absent child gives -inf)
+    float rmax = hi - lo;
+    rmax = fmaxf(rmax, __shfl_xor(rmax, 1));
+    rmax = fmaxf(rmax, __shfl_xor(rmax, 2));
     float *rec = (float *) (out + (size_t) node * 3);
-    if (j == 0) { rec[0] = a; rec[1] = b; rec[2] = c; }
+    if (j == 0) { rec[0] = a; rec[1] = b; rec[2] = c; rec[3] = __builtin_fabsf(a) + __builtin_fabsf(b) + fmaxf(rmax, 0.f); }
     rec[4 + 2 * j] = lo; rec[5 + 2 * j] = hi;
 }
 // Fourth entry of the record: what the walk multiplies its xy uncertainty m by to get a z uncertainty -- the slope
 // of the plane, |a|+|b| per cell, PLUS the largest sheared range of a child: the triangle test may report a hit up
 // to m cells beside the walk's ray (that is what m stands for), and where the surface is far steeper than the plane
 // (a needle triangle) those m cells are up to m x range up or down.
-__global__ __launch_bounds__(HF_BLOCK) void hf_shear_slope_kernel(int sh, float4 *__restrict__ out) {
-    const int node = blockIdx.x * HF_BLOCK + threadIdx.x;
-    if (node >= (1 << (2 * sh))) return;
-    float4 *rec = out + (size_t) node * 3;
-    const float4 pl = rec[0], q01 = rec[1], q23 = rec[2];
-    const float rmax = fmaxf(fmaxf(fmaxf(q01.y - q01.x, q01.w - q01.z), fmaxf(q23.y - q23.x, q23.w - q23.z)), 0.f); // absent: -inf
-    rec[0].w = __builtin_fabsf(pl.x) + __builtin_fabsf(pl.y) + rmax;
-}
+// (computed by hf_shear_kernel / hf_shear_level1_kernel with the ranges.)
 
 // Level 1 (three quarters of all records, 201 MB at N = 4096): one thread per node -- the 3x3 vertex window is read
 // once, the four children are the cells themselves, the slope factor is computed in the same pass and the record is
-// written as three 16-byte stores.  Same arithmetic as hf_shear_kernel + hf_shear_slope_kernel with L = 1.
+// written as three 16-byte stores.  Same arithmetic as hf_shear_kernel with L = 1.
 // The same window also gives the node's entry of the min/max pyramid (hf_mip_level1_kernel's value: clamping only
 // repeats vertices of existing cells), written when mip1 is not null.
 __global__ __launch_bounds__(HF_BLOCK) void hf_shear_level1_kernel(const float *__restrict__ h, int W, int H, float s,
@@ -231,7 +229,6 @@ void hf_launch_build_mips(const hf_dev_field &f, float2 *mip, float4 *shear, hip
         }
         hipLaunchKernelGGL(hf_shear_kernel, dim3((4 * n + HF_BLOCK - 1) / HF_BLOCK), dim3(HF_BLOCK), 0, stream, f.h, f.W,
                            f.H, f.s, L, k, recs);
-        hipLaunchKernelGGL(hf_shear_slope_kernel, dim3((n + HF_BLOCK - 1) / HF_BLOCK), dim3(HF_BLOCK), 0, stream, k, recs);
     }
     (void) hipMemsetAsync(mip, 0, sizeof(float2), stream); // padding entry
     // depths <= ktop of the pyramid and their records come from one launch at the end (hf_mip_top_kernel); every level
