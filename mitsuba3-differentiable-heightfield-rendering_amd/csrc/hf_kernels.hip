@@ -736,10 +736,17 @@ __device__ __forceinline__ void walk_rows(const hf_dev_field &f, const hf_ray_st
             imax = wave_max_u32(in_row ? (uint32_t) fminf(fmaxf(xb2 * iS, 0.f), lim) : 0u);
         }
         const uint32_t aj = fy ? nn - 1u - j : j;
+        // Any-hit mode: lowest point of this lane's fat ray inside the row slab -- a node whose maximum lies below it
+        // for every lane is skipped on one comparison (three quarters of the enumerated nodes are rejected for being
+        // below the rays).  ray_test 2.54 -> 2.45 ms; in the closest-hit modes the extra live register costs what the
+        // skipped tests save (closest hit +-0, fused +2 %), so they test every node in full.
+        const float zrow = (ANY && in_row) ? fminf(__builtin_fmaf(t0, r.dz, r.gz), __builtin_fmaf(t1, r.dz, r.gz)) - r.mz
+                                           : (ANY ? __builtin_inff() : 0.f);
         for (uint32_t i = imin; i <= imax; ++i) { // wave-uniform
             WCOUNT(1);
             const uint32_t ai = fx ? nn - 1u - i : i;
             const float2 box = lvl[(aj << kd) + ai]; // uniform address: one line, broadcast
+            if (ANY && __ballot(zrow <= box.y) == 0ull) continue;
             const float fX = (float) i * S, fYi = (float) j * S;
             const float xlo = (fX - r.gxm) * r.idx, xhi = (fX + S - r.gxp) * r.idx;
             const float ylo = (fYi - r.gym) * r.idy, yhi = (fYi + S - r.gyp) * r.idy;
