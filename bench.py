@@ -223,7 +223,10 @@ def main():
                     "algorithmic_bytes": {"forward": fwd_bytes, "adjoint": adj_bytes}}
         extras = None
         if world == 1 and os.environ.get("HF_BENCH_EXTRAS", "1") != "0":  # profile_round.sh switches them off
-            extras = other_launches(torch, hf_amd, _capi, lib, shape, rays, r_s, pi_s, si_s, si, R, stream, flags)
+            try:   # the headline line must not depend on the extra timings
+                extras = other_launches(torch, hf_amd, _capi, lib, shape, rays, r_s, pi_s, si_s, si, R, stream, flags)
+            except Exception as e:
+                extras = {"error": repr(e)}
         cpu = None
         if world == 1 and args.cpu_seconds > 0:
             cpu = cpu_baseline(args, heights.cpu().numpy(), rays, gsi, R)
