@@ -229,7 +229,10 @@ def main():
                 extras = {"error": repr(e)}
         cpu = None
         if world == 1 and args.cpu_seconds > 0:
-            cpu = cpu_baseline(args, heights.cpu().numpy(), rays, gsi, R)
+            try:
+                cpu = cpu_baseline(args, heights.cpu().numpy(), rays, gsi, R)
+            except Exception as e:   # e.g. the oracle library could not be built on this host
+                cpu = {"error": repr(e)}
         out = {"metric": "Mrays/s forward+adjoint on 4096^2 heightfield", "value": round(value, 2),
                "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms_step, 4), "higher_is_better": True,
