@@ -26,6 +26,11 @@
  *     hf_set_heights* requires that no query on the same handle is in flight
  *     on another stream (reference: dr::sync_thread() in parameters_changed,
  *     src/shapes/rectangle.cpp:131-142).
+ *   - HIP graphs: the wavefront entry points (device-pointer forms), hf_set_heights and hf_adam_step may be issued
+ *     on a stream that is being captured; they then allocate nothing and record / wait for no event, so one
+ *     optimisation step can be captured once and replayed.  Replays that run concurrently with other work of the
+ *     same handle on other streams are the caller's to order.  Not capturable: hf_create / hf_destroy,
+ *     hf_set_heights_host, hf_bbox, hf_get_mip and the host-pointer packet entry (they synchronise).
  */
 #ifndef HF_H
 #define HF_H

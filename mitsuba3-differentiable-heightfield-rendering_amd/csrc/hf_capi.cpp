@@ -24,14 +24,24 @@ struct hf_field {
     // carries the completion event of the launch that used it last: a launch that re-uses the slot first makes
     // its stream wait for that event (a device-side wait, normally long past), so two pending launches never
     // share a block, and hf_destroy waits for exactly the launches of this handle instead of the whole device.
-    // Blocks are allocated on first use (hf_trace_scratch_bytes).
+    // Blocks are allocated by hf_create (hf_trace_scratch_bytes is a constant today; a larger request re-allocates).
+    // HIP-graph capture: a launch issued while its stream is being captured takes its block from the upper half of
+    // the ring and touches no event (an event recorded inside a capture cannot be waited for outside it, and
+    // vice versa): the captured graph orders its own launches on its stream; replays that run CONCURRENTLY with other
+    // work of the same handle on other streams are the caller's to order, as for any buffer the graph writes.
     char *slot_buf[HF_NUM_SLOTS];
     size_t slot_cap[HF_NUM_SLOTS];
     hipEvent_t slot_done[HF_NUM_SLOTS];
     bool slot_used[HF_NUM_SLOTS];
-    uint32_t next_slot;
+    uint32_t next_slot, next_capture_slot;
     std::mutex *slot_mutex;
 };
+
+static bool stream_capturing(hipStream_t s) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess) { (void) hipGetLastError(); return false; }
+    return st == hipStreamCaptureStatusActive;
+}
 
 // keeps the caller's current device across a call that has to work on the handle's device
 struct hf_device_guard {
@@ -53,7 +63,12 @@ struct hf_device_guard {
 static void *slot_acquire(const hf_field *hf, hipStream_t stream, size_t bytes, uint32_t *slot) {
     hf_field *m = const_cast<hf_field *>(hf);
     std::lock_guard<std::mutex> lock(*m->slot_mutex);
-    const uint32_t k = m->next_slot++ % HF_NUM_SLOTS;
+    if (stream_capturing(stream)) { // no allocation, no events (see hf_field)
+        const uint32_t k = HF_NUM_SLOTS / 2 + m->next_capture_slot++ % (HF_NUM_SLOTS / 2);
+        *slot = k;
+        return m->slot_cap[k] >= bytes ? m->slot_buf[k] : nullptr;
+    }
+    const uint32_t k = m->next_slot++ % (HF_NUM_SLOTS / 2);
     *slot = k;
     if (m->slot_cap[k] < bytes) { // grow: the previous user must be done before its block goes away
         if (m->slot_used[k]) (void) hipEventSynchronize(m->slot_done[k]);
@@ -70,6 +85,7 @@ static void *slot_acquire(const hf_field *hf, hipStream_t stream, size_t bytes, 
 static void slot_release(const hf_field *hf, hipStream_t stream, uint32_t slot) {
     hf_field *m = const_cast<hf_field *>(hf);
     std::lock_guard<std::mutex> lock(*m->slot_mutex);
+    if (slot >= HF_NUM_SLOTS / 2) return; // a captured launch
     (void) hipEventRecord(m->slot_done[slot], stream);
     m->slot_used[slot] = true;
 }
@@ -190,8 +206,12 @@ extern "C" int hf_create(const hf_desc_t *desc, hf_field_t **out) {
     if (e == hipSuccess) e = hipMalloc((void **) &hf->d_mip, sizeof(float2) * off);
     if (e == hipSuccess) e = hipMalloc((void **) &hf->d_shear, sizeof(float4) * 3 * (hf_shear_records(top) + 1));
     if (e == hipSuccess) e = hipEventCreateWithFlags(&hf->built, hipEventDisableTiming);
-    for (int k = 0; k < HF_NUM_SLOTS && e == hipSuccess; ++k)
+    for (int k = 0; k < HF_NUM_SLOTS && e == hipSuccess; ++k) {
         e = hipEventCreateWithFlags(&hf->slot_done[k], hipEventDisableTiming);
+        const size_t cap = hf_trace_scratch_bytes(0) < 4096 ? 4096 : hf_trace_scratch_bytes(0);
+        if (e == hipSuccess) e = hipMalloc((void **) &hf->slot_buf[k], cap);
+        if (e == hipSuccess) hf->slot_cap[k] = cap;
+    }
     hf->slot_mutex = new (std::nothrow) std::mutex();
     if (e == hipSuccess && !hf->slot_mutex) e = hipErrorOutOfMemory;
     d.h = hf->d_heights;
@@ -235,7 +255,7 @@ extern "C" int hf_set_heights(hf_field_t *hf, const float *d_heights, hf_stream_
         HF_HIP(hipMemcpyAsync(hf->d_heights, d_heights, bytes, hipMemcpyDeviceToDevice, st));
     hf_launch_build_mips(hf->dev, hf->d_mip, hf->d_shear, st);
     HF_HIP(hipGetLastError());
-    HF_HIP(hipEventRecord(hf->built, st));
+    if (!stream_capturing(st)) HF_HIP(hipEventRecord(hf->built, st)); // (a captured rebuild is ordered by its graph)
     return HF_OK;
 }
 
