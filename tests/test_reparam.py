@@ -81,7 +81,8 @@ def test_gpu_reparameterize_ray_matches_oracle(hf, oracle, kappa, antithetic, nu
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kappa,antithetic,num_rays", [(30.0, False, 5), (2000.0, True, 8), (1e5, False, 4)])
+@pytest.mark.parametrize("kappa,antithetic,num_rays", [(30.0, False, 5), (2000.0, True, 8), (1e5, False, 4),
+                                                       (1e4, False, 1), (500.0, True, 32)])
 def test_gpu_fused_loops_equal_the_per_sample_kernels(hf, kappa, antithetic, num_rays):
     """hf_reparam_backward (one kernel for all samples; the default when only the heights are differentiated) against
     hf_reparam_aux_rays / hf_reparam_weights / hf_adjoint per sample: the same arithmetic, so the only difference is
