@@ -118,7 +118,8 @@ def lib():
     """Load libhf.so; fails loudly if it is missing -- there is no fallback path."""
     global _lib
     if _lib is None:
-        path = _build.LIB_PATH
+        # HF_LIB: another build of the SAME library (scripts/vb.sh variants for A/B measurements), never a fallback
+        path = os.environ.get("HF_LIB") or _build.LIB_PATH
         if not os.path.exists(path):
             raise ImportError(
                 f"{path} is missing: build it with `python __graft_entry__.py` (hipcc, gfx950). "

@@ -97,7 +97,9 @@ __host__ __device__ __forceinline__ uint32_t hf_depth_off(int k) { return (0x555
 // stored); record = { (a, b, c, |a|+|b|), (lo0, hi0, lo1, hi1), (lo2, hi2, lo3, hi3) }, children in
 // actual order j = 2 jy + jx, absent children (+inf, -inf).  Same coarse-first indexing as the
 // pyramid: node (ix,iy) of level L = depth k = top - L is record  hf_depth_off(k) - 1 + (iy << k) + ix.
+#ifndef HF_SHEAR_TOP
 #define HF_SHEAR_TOP 5
+#endif
 __host__ __device__ __forceinline__ size_t hf_shear_records(int top) { // depths 0 .. top-1 (levels 1 .. top)
     return (size_t) hf_depth_off(top) - 1u;
 }

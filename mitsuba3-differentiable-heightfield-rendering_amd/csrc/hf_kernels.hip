@@ -29,6 +29,15 @@
 #include "hf_launch.h"
 
 #define HF_BLOCK 256
+#ifndef HF_HOIST
+#define HF_HOIST 0
+#endif
+#ifndef HF_XCD_CHUNK
+#define HF_XCD_CHUNK 1u // consecutive grabs that go to the same XCD (power of two)
+#endif
+#ifndef HF_TWO_FRONT
+#define HF_TWO_FRONT 1
+#endif
 #ifndef HF_SUBTREE_LEVEL
 #define HF_SUBTREE_LEVEL 5 // the shared walk hands nodes of this level (32x32 cells) to the per-lane walk
 #endif
@@ -450,6 +459,10 @@ __device__ __forceinline__ void walk_init(hf_walk &w, uint32_t X0, uint32_t Y0, 
     w.X = X0 >> 1; w.Y = Y0 >> 1; w.cur = 1u << ((X0 & 1u) | ((Y0 & 1u) << 1)); w.pend = 0u;
     w.stk = 0ull; w.L = L0 + 1; w.pc0 = 0; w.pr0 = 0; w.fin = false;
 }
+// start AT node (X0,Y0) of level L0 whose record the caller has already evaluated: cur0 = its order-space children to visit
+__device__ __forceinline__ void walk_init_at(hf_walk &w, uint32_t X0, uint32_t Y0, int L0, uint32_t cur0) {
+    w.X = X0; w.Y = Y0; w.cur = cur0; w.pend = 0u; w.stk = 0ull; w.L = L0; w.pc0 = 0; w.pr0 = 0; w.fin = false;
+}
 __device__ __forceinline__ void walk_idle(hf_walk &w) {
     w.X = 0u; w.Y = 0u; w.cur = 0u; w.pend = 0u; w.stk = 0ull; w.L = 0; w.pc0 = 0; w.pr0 = 0; w.fin = true;
 }
@@ -547,120 +560,18 @@ __device__ __forceinline__ bool walk_subtree(const hf_dev_field &f, const Src &s
     return hit_any;
 }
 
-// Wave-coherent walk: the 64 rays of the wave share ONE depth-first walk of the upper
-// quadtree levels.  Node coordinates, level, pending-children masks and the mask stack are
-// wave-uniform (SGPRs / scalar unit); each lane only tests its own fat ray against the four
-// child boxes of the current node, and a child is entered when ANY lane overlaps it (ballot).
-// Nodes of level HF_SUBTREE_LEVEL -- about the footprint of one pixel's rays -- are handed
-// to the per-lane walk of every lane that overlaps them.  Children are visited front to back
-// in the common order space, which requires equal direction signs in the wave (checked by the
-// caller).  Per-lane results equal a purely per-lane walk's: every node a lane's ray overlaps
-// is visited because all its ancestors overlap that ray too.
-
-template <bool ANY>
-__device__ __forceinline__ void walk_packet(const hf_dev_field &f, const hf_ray_state &rs, bool alive, bool coherent, bool fx, bool fy,
-                                            hf_hit &best) {
-    const hf_trav &r = rs.r;
-    const int top = f.top;
-    float thi = alive ? rs.thi : -1.f; // dead lanes overlap nothing
-    const uint32_t fxm = fx ? ((1u << top) - 1u) : 0u, fym = fy ? ((1u << top) - 1u) : 0u;
-    const float2 *__restrict__ mip = f.mip;
-    uint32_t X = 0, Y = 0, cur = 1u; // cur: order-space children of (X,Y,L) still to visit
-    int L = top + 1;                 // virtual node above the root whose only child (k = 0) is the root
-    uint64_t stk = 0;
-    uint32_t ml = alive ? 1u : 0u;   // per-lane overlap mask (ACTUAL child numbering) of the current node
-#ifdef HF_TSTATS
-    long long tsub = 0;
-#endif
-#ifdef HF_WSTATS
-    if ((threadIdx.x & 63u) < 8u) wcnt_base()[threadIdx.x & 63u] = 0u;
-#endif
-    for (;;) {
-        // The state of the shared walk is wave-uniform by construction (it only ever depends on ballots), but the
-        // compiler's divergence analysis gives up on it across the per-lane walks inside this loop and would keep it
-        // -- and all the node addressing that derives from it -- in vector registers (flat loads, vector integer
-        // maths).  Reading it through the first lane pins it to scalar registers: scalar address arithmetic, LDS /
-        // scalar-cache loads with a uniform address, scalar branches.
-        X = (uint32_t) __builtin_amdgcn_readfirstlane((int) X); Y = (uint32_t) __builtin_amdgcn_readfirstlane((int) Y);
-        cur = (uint32_t) __builtin_amdgcn_readfirstlane((int) cur); L = __builtin_amdgcn_readfirstlane(L);
-        stk = ((uint64_t) (uint32_t) __builtin_amdgcn_readfirstlane((int) (stk >> 32)) << 32) |
-              (uint64_t) (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) stk);
-        while (cur == 0u) { // node exhausted: pop
-            if (L > top) goto done;
-            cur = (uint32_t) stk & 15u; stk >>= 4;
-            X >>= 1; Y >>= 1; ++L;
-        }
-        const uint32_t k = (uint32_t) __builtin_ctz(cur);
-        cur &= cur - 1u;
-        WCOUNT(1);
-        const uint32_t cx = 2u * X + (k & 1u), cy = 2u * Y + (k >> 1); // child, level L-1
-        if (ANY && __ballot(thi >= 0.f) == 0ull) goto done;
-        if (L - 1 <= (coherent ? HF_SUBTREE_LEVEL : top)) {
-            // hand the node to the lanes whose ray overlaps it (incoherent wave: the root, to every live lane)
-            const uint32_t j = k ^ ((fx ? 1u : 0u) | (fy ? 2u : 0u));
-            const float S = (float) (1u << (L - 1));
-            const float te = fmaxf(((float) cx * S - r.gxm) * r.idx, ((float) cy * S - r.gym) * r.idy);
-            const bool mine = (L > top) ? (thi >= 0.f) : ((((ml >> j) & 1u) != 0u) & (te <= thi));
-            if (__ballot(mine) == 0ull) continue;
-            WCOUNT(2);
-            const int L0 = L - 1;
-            hf_src_global src;
-            src.mip = f.mip; src.shear = f.shear; src.h = f.h; src.top = f.top; src.W = f.W;
-#ifdef HF_TSTATS
-            const long long ts0 = clock64();
-#endif
-            if (mine) {
-                // per-lane mirror flags: equal to (fx,fy) in a coherent wave, arbitrary otherwise
-                const uint32_t lfxm = rs.fx ? ((1u << top) - 1u) : 0u, lfym = rs.fy ? ((1u << top) - 1u) : 0u;
-                const bool h = walk_subtree<ANY>(f, src, rs, r, rs.fx, rs.fy, lfxm, lfym, cx, cy, L0, thi, best);
-                if (ANY && h) thi = -1.f;
-            }
-#ifdef HF_TSTATS
-            tsub += clock64() - ts0;
-#endif
-            continue;
-        }
-        // inner node (cx,cy) of level L-1.  Its mask bit may predate the hits found since: skip it when no
-        // lane can still reach it before its current t_hi
-        {
-            const float Sn = (float) (1u << (L - 1));
-            const float ten = fmaxf(((float) cx * Sn - r.gxm) * r.idx, ((float) cy * Sn - r.gym) * r.idy);
-            if (__ballot(ten <= thi) == 0ull) continue;
-        }
-        // fetch its four child boxes (uniform address), per-lane overlap
-        stk = (stk << 4) | (uint64_t) cur;
-        X = cx; Y = cy; --L;
-        WCOUNT(0);
-        {
-            hf_quad q;
-            {   // children boxes: the two x-adjacent children of a row are one aligned 16-byte entry pair (hf_depth_off)
-                const uint32_t kd = (uint32_t) (top - (L - 1));
-                const uint32_t ix = X ^ (fxm >> L), iy = Y ^ (fym >> L);
-                const uint32_t base = hf_depth_off((int) kd) + ((2u * iy) << kd) + 2u * ix;
-                // a scalar (uniform) global address: one cache line, broadcast to the wave (an LDS-staged copy of
-                // the top of the pyramid measured the same and is gone)
-                const uint32_t ub0 = (uint32_t) __builtin_amdgcn_readfirstlane((int) base);
-                const float4 c01 = *(const float4 *) (mip + ub0);
-                const float4 c23 = *(const float4 *) (mip + ub0 + (1u << kd));
-                q.lo[0] = c01.x; q.hi[0] = c01.y; q.lo[1] = c01.z; q.hi[1] = c01.w;
-                q.lo[2] = c23.x; q.hi[2] = c23.y; q.lo[3] = c23.z; q.hi[3] = c23.w;
-            }
-            const float S = (float) (1u << (L - 1));
-            ml = child_mask(r, fx, fy, (float) X * (S + S), (float) Y * (S + S), S, q, r.gz, r.dz, r.mz, thi);
-            uint32_t ma = 0;
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) ma |= (__ballot((ml >> jj) & 1u) != 0ull) ? (1u << jj) : 0u;
-            cur = to_order(ma, fx, fy);
-        }
-    }
-done:;
-#ifdef HF_TSTATS // diagnostic build (scripts/tstats.py): cycles spent in the per-lane walks of this batch
-    if (alive) { best.hit = true; best.u = (float) tsub; }
-#endif
-#ifdef HF_WSTATS
-    if (alive) { const uint32_t *c = wcnt_base(); best.hit = true; best.t = (float) c[0] + 1024.f * (float) c[1] + 1048576.f * (float) c[2];
-        best.u = (float) c[3] + 4096.f * (float) c[4]; best.v = (float) c[5] + 4096.f * (float) c[6]; }
-#endif
+// the same walk below a node whose own record the caller has evaluated (cur0: its order-space children to visit)
+template <bool ANY, typename Src>
+__device__ __forceinline__ bool walk_subtree_from(const hf_dev_field &f, const Src &src, const hf_ray_state &rs,
+                                                  const hf_trav &r, bool fx, bool fy, uint32_t fxm, uint32_t fym,
+                                                  uint32_t X0, uint32_t Y0, int L0, uint32_t cur0, float &thi, hf_hit &best) {
+    hf_walk w;
+    walk_init_at(w, X0, Y0, L0, cur0);
+    bool hit_any = false;
+    do {
+        hit_any |= walk_round<ANY>(f, src, rs, r, fx, fy, fxm, fym, thi, best, w);
+    } while (__ballot(!w.fin) != 0ull);
+    return hit_any;
 }
 
 // wave-wide minimum / maximum of an unsigned value, result scalar (DPP within rows of 16, readlane across rows);
@@ -758,10 +669,35 @@ __device__ __forceinline__ void walk_rows(const hf_dev_field &f, const hf_ray_st
 #ifdef HF_TSTATS
             const long long ts0 = clock64();
 #endif
+#if HF_HOIST
+            // The node's own record is evaluated HERE, for all lanes at once (uniform address: scalar loads), instead
+            // of as the first visit of the per-lane walk: a node the rays only skim -- its box overlaps, its children's
+            // sheared ranges do not -- is dropped without a hand-off, and every hand-off is one iteration shorter.
+            uint32_t cur0 = 0u;
+            {
+                const float4 *rec = src.sheared(HF_SUBTREE_LEVEL, ai, aj);
+                const float4 pl = rec[0], q01 = rec[1], q23 = rec[2];
+                const float Sc = 0.5f * S;
+                float gz, dz, mz;
+                shear_line(f, rs, fx, fy, pl.x, pl.y, pl.z, pl.w, fX + Sc, fYi + Sc, gz, dz, mz);
+                hf_quad q;
+                q.lo[0] = q01.x; q.hi[0] = q01.y; q.lo[1] = q01.z; q.hi[1] = q01.w;
+                q.lo[2] = q23.x; q.hi[2] = q23.y; q.lo[3] = q23.z; q.hi[3] = q23.w;
+                const uint32_t m4 = child_mask(r, fx, fy, fX, fYi, Sc, q, gz, dz, mz, thi);
+                cur0 = mine ? to_order(m4, fx, fy) : 0u;
+            }
+            if (__ballot(cur0 != 0u) == 0ull) continue;
+            WCOUNT(4);
+            if (cur0 != 0u) {
+                const bool h = walk_subtree_from<ANY>(f, src, rs, r, rs.fx, rs.fy, lfxm, lfym, i, j, HF_SUBTREE_LEVEL, cur0, thi, best);
+                if (ANY && h) thi = -1.f;
+            }
+#else
             if (mine) {
                 const bool h = walk_subtree<ANY>(f, src, rs, r, rs.fx, rs.fy, lfxm, lfym, i, j, HF_SUBTREE_LEVEL, thi, best);
                 if (ANY && h) thi = -1.f;
             }
+#endif
 #ifdef HF_TSTATS
             tsub += clock64() - ts0;
 #endif
@@ -870,9 +806,6 @@ __device__ __forceinline__ void miss_si(hf_si_rec &si, v3 d, uint32_t flags) {
 #endif
 #ifndef HF_COH_DIR
 #define HF_COH_DIR 0.05f   // ... and the xy direction ratios within this relative distance
-#endif
-#ifndef HF_ROW_SWEEP
-#define HF_ROW_SWEEP 1
 #endif
 #ifndef HF_TRACE_WAVES_FUSED
 #define HF_TRACE_WAVES_FUSED 5 // ... of the fused mode: its surface-interaction tail needs ~100 registers (6 waves: 30 spills, slower)
@@ -993,13 +926,17 @@ __global__ __launch_bounds__(HF_BLOCK, (MODE == 2 ? HF_TRACE_WAVES_FUSED : HF_TR
         if (lane == 0) g = atomicAdd(counter + (size_t) xc * HF_COUNTER_STRIDE, 1ull);
         g = ((unsigned long long) (uint32_t) __builtin_amdgcn_readfirstlane((int) (g >> 32)) << 32) |
             (unsigned long long) (uint32_t) __builtin_amdgcn_readfirstlane((int) (g & 0xffffffffull));
-        const unsigned long long gg = g * HF_NUM_XCD + xc;
+        const unsigned long long gg = ((g / HF_XCD_CHUNK) * HF_NUM_XCD + xc) * HF_XCD_CHUNK + (g % HF_XCD_CHUNK);
         if (gg >= n_grabs) {
             if (++tried == HF_NUM_XCD) break;
             xc = (xc + 1u) & (HF_NUM_XCD - 1u);
             continue;
         }
+#if HF_TWO_FRONT
         const unsigned long long base = ((gg & 1ull) ? (n_grabs >> 1) - 1ull - (gg >> 1) : (n_grabs >> 1) + (gg >> 1)) * grab;
+#else
+        const unsigned long long base = gg * grab;
+#endif
         // the ray of the batch in flight: requested one batch ahead (see below)
         v3 o = mk3(0.f, 0.f, 0.f), d = o;
         float maxt = 0.f;
@@ -1066,7 +1003,6 @@ __global__ __launch_bounds__(HF_BLOCK, (MODE == 2 ? HF_TRACE_WAVES_FUSED : HF_TR
 #ifdef HF_TSTATS
                 const long long tb1 = clock64();
 #endif
-#if HF_ROW_SWEEP
                 if (coherent && f.top > HF_SUBTREE_LEVEL) {
                     walk_rows<MODE == 1>(f, rs, alive, fx0, fy0, best);
                 } else if (alive) {
@@ -1077,9 +1013,6 @@ __global__ __launch_bounds__(HF_BLOCK, (MODE == 2 ? HF_TRACE_WAVES_FUSED : HF_TR
                     float thi = rs.thi;
                     (void) walk_subtree<MODE == 1>(f, src, rs, rs.r, rs.fx, rs.fy, lfxm, lfym, 0u, 0u, f.top, thi, best);
                 }
-#else
-                walk_packet<MODE == 1>(f, rs, alive, coherent, fx0, fy0, best);
-#endif
 #ifdef HF_TSTATS
                 if (alive) { best.t = (float) (clock64() - tb0); best.v = (float) (tb1 - tb0); }
 #endif

@@ -416,6 +416,84 @@ static void trace_hier(const hfo_field *f, const float o[3], const float d[3], f
     }
 }
 
+
+/*
+ * BAND brute force: an intersector that shares NOTHING with the hierarchical walk -- no mips, no xy margin m, no
+ * z margin mz, none of their constants.  In float64: the object-space ray in cell units, its parameter range
+ * clipped to the grid's xy extent grown by HFO_BAND cells and to the global height range grown by 1 % of its span
+ * (+1e-3; the walk's own clip uses 1e-5), both ends then pushed out by HFO_BAND cells along xy; every cell whose
+ * xy box lies within +/-HFO_BAND cells of that segment is tested with the same fp32 test_cell and tie rule as the
+ * brute force over all cells (kdtree.h:2424-2448).  A cell farther than two cells from the ray's line cannot pass the
+ * fp32 Moeller-Trumbore test at any grid size this library supports, so the result is the full brute force's --
+ * checked against it directly on the small grids where that one is affordable (tests/test_oracle_band.py) -- and
+ * it stays affordable at the BASELINE grid sizes (N = 1024 ... 4096), where it pins the hierarchical walks of the
+ * oracle and of the HIP kernels (accelerated == naive on the real scene: src/render/tests/test_kdtrees.py:52-82).
+ */
+#define HFO_BAND 2
+static void trace_band(const hfo_field *f, const float o[3], const float d[3], float maxt,
+                       int any_hit, best_t *b) {
+    float oo[3], od[3];
+    xform_point(f->to_object, o, oo);
+    xform_vec(f->to_object, d, od);
+    b->hit = 0; b->t = INFINITY; b->u = b->v = 0.f; b->prim = 0;
+    if (!finite3(oo) || !finite3(od) || !(maxt >= 0.f)) return;
+    if (od[0] == 0.f && od[1] == 0.f && od[2] == 0.f) return;   /* null direction: every test is NaN */
+    const int cw = f->W - 1, ch = f->H - 1;
+    const double B = (double) HFO_BAND;
+    const double g[3] = { ((double) oo[0] + 1.0) * 0.5 * cw, ((double) oo[1] + 1.0) * 0.5 * ch, (double) oo[2] };
+    const double e[3] = { (double) od[0] * 0.5 * cw, (double) od[1] * 0.5 * ch, (double) od[2] };
+    const double span = (double) f->zmax - (double) f->zmin;
+    const double zpad = 1e-2 * span + 1e-3 * (fabs((double) f->zmin) + fabs((double) f->zmax)) + 1e-30;
+    const double lo[3] = { -B, -B, (double) f->zmin - zpad };
+    const double hi[3] = { cw + B, ch + B, (double) f->zmax + zpad };
+    double t0 = 0.0, t1 = (double) maxt;
+    for (int k = 0; k < 3; ++k) {
+        if (e[k] == 0.0) {
+            if (g[k] < lo[k] || g[k] > hi[k]) return;
+        } else {
+            const double a = (lo[k] - g[k]) / e[k], c = (hi[k] - g[k]) / e[k];
+            t0 = fmax(t0, fmin(a, c));
+            t1 = fmin(t1, fmax(a, c));
+        }
+    }
+    if (!(t0 <= t1)) return;
+    const double sxy = hypot(e[0], e[1]);
+    if (sxy > 0.0) {                       /* both ends out by B cells along xy (t0 may become negative: the */
+        const double ext = B / sxy;        /* triangle test's own t >= 0 decides) */
+        if (isfinite(ext)) { t0 -= ext; t1 += ext; }
+    }
+    if (!isfinite(t1) || !isfinite(t0)) return;  /* (cannot happen: a non-null direction bounds t1 through a slab above) */
+    const double xa = g[0] + t0 * e[0], xb = g[0] + t1 * e[0];
+    const double ya = g[1] + t0 * e[1], yb = g[1] + t1 * e[1];
+    const int xmajor = fabs(xb - xa) >= fabs(yb - ya);
+    /* u = major axis, w = minor axis */
+    const double ua = xmajor ? xa : ya, ub = xmajor ? xb : yb;
+    const double gu = xmajor ? g[0] : g[1], eu = xmajor ? e[0] : e[1];
+    const double gw = xmajor ? g[1] : g[0], ew = xmajor ? e[1] : e[0];
+    const int nu = xmajor ? cw : ch, nw = xmajor ? ch : cw;
+    int cu0 = (int) floor(fmin(ua, ub)) - HFO_BAND, cu1 = (int) floor(fmax(ua, ub)) + HFO_BAND;
+    if (cu0 < 0) cu0 = 0;
+    if (cu1 > nu - 1) cu1 = nu - 1;
+    for (int cu = cu0; cu <= cu1; ++cu) {
+        double wa, wb;
+        if (eu == 0.0) { wa = gw + t0 * ew; wb = gw + t1 * ew; }
+        else {
+            double ta = ((double) cu - B - gu) / eu, tb = ((double) cu + 1.0 + B - gu) / eu;
+            if (ta > tb) { const double q = ta; ta = tb; tb = q; }
+            ta = fmax(ta, t0); tb = fmin(tb, t1);
+            if (ta > tb) continue;
+            wa = gw + ta * ew; wb = gw + tb * ew;
+        }
+        int cv0 = (int) floor(fmin(wa, wb)) - HFO_BAND, cv1 = (int) floor(fmax(wa, wb)) + HFO_BAND;
+        if (cv0 < 0) cv0 = 0;
+        if (cv1 > nw - 1) cv1 = nw - 1;
+        for (int cv = cv0; cv <= cv1; ++cv) {
+            const int cx = xmajor ? cu : cv, cy = xmajor ? cv : cu;
+            if (test_cell(f, cx, cy, oo, od, maxt, b) && any_hit) return;
+        }
+    }
+}
+
 void hfo_intersect_naive(const hfo_field *f, const float o[3], const float d[3], float maxt,
                          float *t, float uv[2], uint32_t *prim) {
     best_t b; trace_naive(f, o, d, maxt, 0, &b); write_result(&b, t, uv, prim);
@@ -432,6 +510,13 @@ void hfo_trace_stats(const hfo_field *f, const float o[3], const float d[3], flo
 /* ray_test == ray_intersect_preliminary(...).is_valid(), src/render/shape.cpp:430-434 */
 int hfo_ray_test_naive(const hfo_field *f, const float o[3], const float d[3], float maxt) {
     best_t b; trace_naive(f, o, d, maxt, 1, &b); return b.hit;
+}
+void hfo_intersect_band(const hfo_field *f, const float o[3], const float d[3], float maxt,
+                        float *t, float uv[2], uint32_t *prim) {
+    best_t b; trace_band(f, o, d, maxt, 0, &b); write_result(&b, t, uv, prim);
+}
+int hfo_ray_test_band(const hfo_field *f, const float o[3], const float d[3], float maxt) {
+    best_t b; trace_band(f, o, d, maxt, 1, &b); return b.hit;
 }
 int hfo_ray_test(const hfo_field *f, const float o[3], const float d[3], float maxt) {
     best_t b; trace_hier(f, o, d, maxt, 1, &b); return b.hit;
@@ -768,8 +853,9 @@ void hfo_intersect_batch(const hfo_field *f, int64_t n, const float *const rays[
         b.hit = 0;
         if (!active || active[i]) {
             float o[3] = { rays[0][i], rays[1][i], rays[2][i] }, d[3] = { rays[3][i], rays[4][i], rays[5][i] };
-            if (mode == 1) trace_naive(f, o, d, rays[6][i], 0, &b);
-            else           trace_hier(f, o, d, rays[6][i], 0, &b);
+            if (mode == 1)      trace_naive(f, o, d, rays[6][i], 0, &b);
+            else if (mode == 2) trace_band(f, o, d, rays[6][i], 0, &b);
+            else                trace_hier(f, o, d, rays[6][i], 0, &b);
         }
         float uv[2];
         write_result(&b, &t[i], uv, &prim[i]);
@@ -786,8 +872,9 @@ void hfo_ray_test_batch(const hfo_field *f, int64_t n, const float *const rays[7
         b.hit = 0;
         if (!active || active[i]) {
             float o[3] = { rays[0][i], rays[1][i], rays[2][i] }, d[3] = { rays[3][i], rays[4][i], rays[5][i] };
-            if (mode == 1) trace_naive(f, o, d, rays[6][i], 1, &b);
-            else           trace_hier(f, o, d, rays[6][i], 1, &b);
+            if (mode == 1)      trace_naive(f, o, d, rays[6][i], 1, &b);
+            else if (mode == 2) trace_band(f, o, d, rays[6][i], 1, &b);
+            else                trace_hier(f, o, d, rays[6][i], 1, &b);
         }
         hit[i] = (uint8_t) b.hit;
     }

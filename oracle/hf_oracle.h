@@ -113,6 +113,11 @@ void hfo_intersect(const hfo_field *f, const float o[3], const float d[3],
 /* number of quadtree nodes visited / cells tested by hfo_intersect for one ray (tuning aid) */
 void hfo_trace_stats(const hfo_field *f, const float o[3], const float d[3], float maxt,
                      uint32_t *nodes, uint32_t *leaves);
+/* brute force over the cells within +/-2 cells of the ray's xy segment (float64 geometry, no mips, no margins shared
+ * with the hierarchical walk): the independent check at grid sizes where the full brute force is unaffordable */
+void hfo_intersect_band(const hfo_field *f, const float o[3], const float d[3],
+                        float maxt, float *t, float uv[2], uint32_t *prim);
+int  hfo_ray_test_band(const hfo_field *f, const float o[3], const float d[3], float maxt);
 int  hfo_ray_test_naive(const hfo_field *f, const float o[3], const float d[3], float maxt);
 int  hfo_ray_test(const hfo_field *f, const float o[3], const float d[3], float maxt);
 
@@ -130,7 +135,7 @@ int hfo_adjoint(const hfo_field *f, const float o[3], const float d[3],
 
 /* --- batched SoA entry points (OpenMP over rays) -------------------------- */
 /* rays: 7 arrays of n floats (ox,oy,oz,dx,dy,dz,maxt). mode: 0 = hierarchical,
- * 1 = brute force.  active may be NULL. */
+ * 1 = brute force, 2 = band brute force.  active may be NULL. */
 void hfo_intersect_batch(const hfo_field *f, int64_t n, const float *const rays[7],
                          const uint8_t *active, int mode, int nthreads,
                          float *t, float *u, float *v, uint32_t *prim);

@@ -149,7 +149,10 @@ class OracleField:
         assert a.shape == (n,)
         return a, a.ctypes.data_as(_u8p)
 
-    def ray_intersect_preliminary(self, rays, active=None, naive=False, nthreads=0):
+    def ray_intersect_preliminary(self, rays, active=None, naive=False, nthreads=0, band=False):
+        """naive: brute force over every cell; band: brute force over the cells within +/-2 cells of the ray's xy
+        segment (independent of the hierarchical walk: no mips, no margins), affordable at BASELINE grid sizes"""
+        naive = 2 if band else int(naive)
         r, arr = self._rays(rays)
         n = r.shape[1]
         a, ap = self._mask(active, n)
@@ -159,7 +162,8 @@ class OracleField:
                                   prim.ctypes.data_as(_u32p))
         return t, u, v, prim
 
-    def ray_test(self, rays, active=None, naive=False, nthreads=0):
+    def ray_test(self, rays, active=None, naive=False, nthreads=0, band=False):
+        naive = 2 if band else int(naive)
         r, arr = self._rays(rays)
         n = r.shape[1]
         a, ap = self._mask(active, n)

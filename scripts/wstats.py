@@ -20,4 +20,4 @@ u, v, t = u[w], v[w], t[w]
 def m(x): return float(x.mean())
 print(f"batches {int(w.sum())}")
 print(f"row sweep: rows with a lane inside {m(t % 1024):.1f}, nodes box-tested {m(torch.floor(t / 1024) % 1024):.1f}, hand-offs with work {m(torch.floor(t / 1048576)):.1f}")
-print(f"subtree (max over lanes of per-call sums; lanes run the same wave-level loop): iterations {m(u % 4096):.1f}, active lanes summed over the visits {m(torch.floor(u / 4096)):.1f}, visits {m(v % 4096):.1f}, cell rounds {m(torch.floor(v / 4096)):.1f}")
+print(f"subtree (max over lanes of per-call sums; lanes run the same wave-level loop): iterations {m(u % 4096):.1f}, hand-offs after the hoisted visit (HF_HOIST builds) {m(torch.floor(u / 4096)):.1f}, visits {m(v % 4096):.1f}, cell rounds {m(torch.floor(v / 4096)):.1f}")

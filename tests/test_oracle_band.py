@@ -1,0 +1,92 @@
+"""The oracle's BAND brute force (oracle/hf_oracle.c: trace_band) -- the independent check of the hierarchical
+walks at grid sizes where the brute force over every cell is unaffordable.
+
+Methodology of the reference: accelerated == naive on the real scene (src/render/tests/test_kdtrees.py:52-82,
+include/mitsuba/render/kdtree.h:2424-2448).  The band intersector shares no mip, margin or constant with the walks
+(float64 geometry, every cell within +/-2 cells of the ray's xy segment, the same fp32 triangle test and tie rule):
+  1. band == brute force over ALL cells, bit for bit, on the small grids where the latter runs (random, secondary-like
+     and grid-aligned degenerate rays incl. negative zeros, affine to_world);
+  2. hierarchical oracle walk == band at the BASELINE grid sizes N = 1024 and N = 4096 on mixed rays (coherent
+     packets from up to 50 units away, grazing packets, random and secondary-like rays).
+The GPU twins (HIP == band on samples of configs[1], configs[3] and the bounce rays) are in tests/test_gpu_band.py.
+"""
+import numpy as np
+import pytest
+
+import common
+from oracle import hf_oracle as O
+
+
+def _same(a, b):
+    t0, u0, v0, p0 = a
+    t1, u1, v1, p1 = b
+    assert np.array_equal(p0, p1), f"{int((p0 != p1).sum())} prim_index mismatches"
+    assert np.array_equal(t0.view(np.uint32), t1.view(np.uint32))
+    assert np.array_equal(u0.view(np.uint32), u1.view(np.uint32))
+    assert np.array_equal(v0.view(np.uint32), v1.view(np.uint32))
+
+
+@pytest.mark.parametrize("kind,W,H,tw", [("rand", 33, 21, None), ("sine", 64, 64, None), ("stairs", 40, 17, 3),
+                                         ("flat", 9, 30, None), ("rand", 100, 37, 5), ("rand", 2, 2, None),
+                                         ("rand", 2, 9, 7), ("sine", 129, 65, None)])
+def test_band_equals_full_brute_force(kind, W, H, tw):
+    rng = np.random.default_rng(W * 1000 + H)
+    h = common.heights(kind, W, H, rng)
+    to_world = common.affine(tw) if tw is not None else None
+    f = O.OracleField(h, max_height=0.5, to_world=to_world)
+    xs = np.linspace(-1, 1, W); ys = np.linspace(-1, 1, H)
+    parts = [common.random_rays(3000, rng), common.inside_rays(3000, rng),
+             common.structured_rays(xs[:: max(1, W // 8)], ys[:: max(1, H // 8)])]
+    # far origins: 50 units away, aimed at the grid
+    far = common.random_rays(1000, rng)
+    far[0:3] -= far[3:6] / np.linalg.norm(far[3:6], axis=0) * 50.0
+    parts.append(far)
+    r = common.to_world_rays(np.concatenate(parts, 1), to_world)
+    _same(f.ray_intersect_preliminary(r, band=True), f.ray_intersect_preliminary(r, naive=True))
+    assert np.array_equal(f.ray_test(r, band=True), f.ray_test(r, naive=True))
+
+
+def mixed_rays(rng, n, max_height):
+    """coherent packets (some from 50 units away, some grazing), random and secondary-like rays (object space)"""
+    n1 = n // 4
+    parts = [common.random_rays(n1, rng, max_height), common.inside_rays(n1, rng, max_height)]
+    for graze, dist in ((False, 3.0), (True, 3.0), (False, 50.0), (True, 50.0)):
+        npix = max(1, (n - 2 * n1) // (4 * 64))
+        c = rng.uniform(-1.05, 1.05, (2, npix))
+        dirs = rng.normal(size=(3, npix))
+        dirs[2] = -np.abs(dirs[2]) * (rng.uniform(0.01, 0.1, npix) if graze else rng.uniform(0.2, 1.0, npix))
+        dirs /= np.linalg.norm(dirs, axis=0)
+        o = np.concatenate([c, np.full((1, npix), max_height * 0.5)]) - dirs * dist
+        o = np.repeat(o, 64, 1) + rng.uniform(-1, 1, (3, npix * 64)) * 3e-3
+        d = np.repeat(dirs, 64, 1)
+        parts.append(np.concatenate([o, d, np.full((1, npix * 64), np.inf)]).astype(np.float32))
+    return np.concatenate(parts, 1)
+
+
+def baseline_heights(N):
+    """the bench terrain (SURVEY 8d formula; hf_amd.workload.sine_heights restated in numpy)"""
+    fq = float(min(32.0, max(1.0, 4.0 * N / 64.0)))
+    u = np.arange(N, dtype=np.float64) / (N - 1)
+    U, V = u[None, :], u[:, None]
+    return (0.5 + 0.25 * np.sin(2 * np.pi * fq * U) * np.cos(2 * np.pi * fq * V)
+            + 0.125 * np.sin(2 * np.pi * 7.0 * (U + V))).astype(np.float32)
+
+
+@pytest.mark.parametrize("N,n", [(1024, 120000), (4096, 120000)])
+def test_hierarchical_walk_equals_band_at_baseline_sizes(N, n):
+    rng = np.random.default_rng(N)
+    f = O.OracleField(baseline_heights(N), max_height=0.5)
+    r = mixed_rays(rng, n, 0.5)
+    band = f.ray_intersect_preliminary(r, band=True)
+    _same(f.ray_intersect_preliminary(r), band)
+    assert np.array_equal(f.ray_test(r), np.isfinite(band[0]))
+    assert np.isfinite(band[0]).sum() > n // 10     # the sample does exercise hits
+
+
+def test_hierarchical_walk_equals_band_on_rough_terrain():
+    """white-noise heights (every cell a needle) at N = 1024: the case the needle term of the walk's margin exists for"""
+    rng = np.random.default_rng(7)
+    N = 1024
+    f = O.OracleField(rng.uniform(0, 1, (N, N)).astype(np.float32), max_height=0.05)
+    r = mixed_rays(rng, 40000, 0.05)
+    _same(f.ray_intersect_preliminary(r), f.ray_intersect_preliminary(r, band=True))

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Randomised parity search (tool, not a test): random grids / transforms / ray mixes, every ray's prim_index,
-t and any-hit mask compared bit for bit with the oracle.  usage: fuzz_parity.py [scenes] [rays] [seed]"""
+t and any-hit mask compared bit for bit with the oracle.  usage: fuzz_parity.py [scenes] [rays] [seed]
+FUZZ_BAND=1: the checker is the oracle's BAND brute force (no mips, no margins shared with the walks: trace_band)
+instead of its hierarchical walk; FUZZ_MAXDIM=n: largest grid side (default 700)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -58,7 +60,7 @@ for sc in range(scenes):
     rt = torch.from_numpy(r).cuda()
     ray = hf_amd.Ray3f(rt[0:3].contiguous(), rt[3:6].contiguous(), rt[6].contiguous())
     pi = f_g.ray_intersect_preliminary(ray)
-    t, uu, vv, prim = f_o.ray_intersect_preliminary(r, nthreads=16)
+    t, uu, vv, prim = f_o.ray_intersect_preliminary(r, nthreads=16, band=bool(os.environ.get("FUZZ_BAND")))
     pg, tg = pi.prim_index.cpu().numpy().view(np.uint32), pi.t.cpu().numpy()
     bad = np.nonzero((prim != pg) | (t != tg))[0]
     st = f_g.ray_test(ray).cpu().numpy()
