@@ -28,9 +28,19 @@
  *     src/shapes/rectangle.cpp:131-142).
  *   - HIP graphs: the wavefront entry points (device-pointer forms), hf_set_heights and hf_adam_step may be issued
  *     on a stream that is being captured; they then allocate nothing and record / wait for no event, so one
- *     optimisation step can be captured once and replayed.  Replays that run concurrently with other work of the
- *     same handle on other streams are the caller's to order.  Not capturable: hf_create / hf_destroy,
- *     hf_set_heights_host, hf_bbox, hf_get_mip and the host-pointer packet entry (they synchronise).
+ *     optimisation step can be captured once and replayed.  Limits, all the caller's to honour:
+ *       * every captured trace launch (hf_ray_intersect*, hf_ray_test, hf_reparam_trace) reserves one of 32 scratch
+ *         blocks of the handle for as long as its graph may be replayed; the 33rd is refused with HF_EINVAL.
+ *         hf_capture_reset() hands the blocks back once the graphs captured so far have been destroyed;
+ *       * two graphs of one handle must not be replayed concurrently with each other unless they were captured
+ *         without a reset in between (distinct blocks); replays that run concurrently with other work of the same
+ *         handle on other streams are ordered by the caller, as for any buffer the graph writes;
+ *       * a replayed hf_set_heights / hf_adam_step does not record the handle's "built" event: after such a replay
+ *         synchronise the replay's stream before hf_bbox, hf_get_mip, the packet entry points or hf_destroy;
+ *       * a captured launch snapshots the transform (to_world / to_object) by value: hf_set_transform after the
+ *         capture does not reach the replays -- re-capture.
+ *     Not capturable: hf_create / hf_destroy, hf_set_heights_host, hf_bbox, hf_get_mip and the host-pointer packet
+ *     entry (they synchronise).
  */
 #ifndef HF_H
 #define HF_H
@@ -148,6 +158,10 @@ typedef struct hf_si_grad {
  * (bitmap.cpp:280-283), at most 32768 cells per side and 2^30 vertices (HF_EINVAL beyond). */
 int hf_create(const hf_desc_t *desc, hf_field_t **out);
 int hf_destroy(hf_field_t *hf);
+/* Returns the scratch blocks reserved by captured trace launches (HIP graphs, above) to the handle.  Call it only
+ * when every graph captured from this handle so far has been destroyed or will not be replayed again.  (No
+ * reference counterpart: Dr.Jit owns its kernel-launch scratch; cf. jit_free, src/shapes/rectangle.cpp:330-336.) */
+int hf_capture_reset(hf_field_t *hf);
 
 /* Replaces: parameters_changed({"heightfield"}) (pattern rectangle.cpp:131-142,
  * tensor form src/textures/bitmap.cpp:272-286) + the accel rebuild it triggers

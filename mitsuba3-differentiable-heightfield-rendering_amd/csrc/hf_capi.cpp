@@ -24,11 +24,10 @@ struct hf_field {
     // carries the completion event of the launch that used it last: a launch that re-uses the slot first makes
     // its stream wait for that event (a device-side wait, normally long past), so two pending launches never
     // share a block, and hf_destroy waits for exactly the launches of this handle instead of the whole device.
+    // Choice of the slot, launch and event record are ONE critical section (slot_lease below).
     // Blocks are allocated by hf_create (hf_trace_scratch_bytes is a constant today; a larger request re-allocates).
     // HIP-graph capture: a launch issued while its stream is being captured takes its block from the upper half of
-    // the ring and touches no event (an event recorded inside a capture cannot be waited for outside it, and
-    // vice versa): the captured graph orders its own launches on its stream; replays that run CONCURRENTLY with other
-    // work of the same handle on other streams are the caller's to order, as for any buffer the graph writes.
+    // the ring, touches no event, and keeps the block until hf_capture_reset (slot_lease).
     char *slot_buf[HF_NUM_SLOTS];
     size_t slot_cap[HF_NUM_SLOTS];
     hipEvent_t slot_done[HF_NUM_SLOTS];
@@ -58,37 +57,58 @@ struct hf_device_guard {
     ~hf_device_guard() { if (prev >= 0) (void) hipSetDevice(prev); }
 };
 
-// claims the next scratch slot for a launch on `stream` with at least `bytes` of scratch; *slot receives the slot
-// number for slot_release.  NULL when the block cannot be allocated.
-static void *slot_acquire(const hf_field *hf, hipStream_t stream, size_t bytes, uint32_t *slot) {
-    hf_field *m = const_cast<hf_field *>(hf);
-    std::lock_guard<std::mutex> lock(*m->slot_mutex);
-    if (stream_capturing(stream)) { // no allocation, no events (see hf_field)
-        const uint32_t k = HF_NUM_SLOTS / 2 + m->next_capture_slot++ % (HF_NUM_SLOTS / 2);
-        *slot = k;
-        return m->slot_cap[k] >= bytes ? m->slot_buf[k] : nullptr;
+// Lease of one scratch block for ONE trace launch on `stream`.  The handle's slot mutex is held from the choice of
+// the slot until the launch's completion event has been recorded (the destructor), so the three steps are one
+// critical section: a later lease of the same slot -- from any thread, after the ring has wrapped -- always finds the
+// event of the launch that used the block last and makes its stream wait for it (a device-side wait, normally long
+// past).  The launch itself is asynchronous; the section costs microseconds.  (acquire / launch / record
+// were three sections, and 32 other leases between a thread's acquire and its record could hand the block to a second
+// launch that neither waited for the first nor kept its counters.)
+// Captured launches (the stream is being captured into a HIP graph): the block comes from the upper half of the
+// ring, no event is touched (an event recorded inside a capture cannot be waited for outside it), and every captured
+// launch KEEPS its block for as long as the graph may be replayed: the 33rd captured trace launch of a handle is refused
+// with HF_EINVAL instead of sharing work counters with the first; hf_capture_reset() returns the blocks once the
+// graphs captured so far have been destroyed.
+struct slot_lease {
+    hf_field *m;
+    hipStream_t stream;
+    uint32_t slot = 0;
+    void *buf = nullptr;
+    const char *why = "scratch allocation failed";
+    int code = HF_ENOMEM;
+    std::unique_lock<std::mutex> lock;
+    slot_lease(const hf_field *hf, hipStream_t st, size_t bytes)
+        : m(const_cast<hf_field *>(hf)), stream(st), lock(*const_cast<hf_field *>(hf)->slot_mutex) {
+        if (stream_capturing(stream)) { // no allocation, no events
+            if (m->next_capture_slot >= HF_NUM_SLOTS / 2) {
+                code = HF_EINVAL;
+                why = "more than 32 captured trace launches on this handle (their scratch blocks stay reserved for "
+                      "replays; destroy the graphs and call hf_capture_reset)";
+                return;
+            }
+            slot = HF_NUM_SLOTS / 2 + m->next_capture_slot;
+            if (m->slot_cap[slot] >= bytes) { buf = m->slot_buf[slot]; ++m->next_capture_slot; }
+            return;
+        }
+        slot = m->next_slot++ % (HF_NUM_SLOTS / 2);
+        if (m->slot_cap[slot] < bytes) { // grow: the previous user must be done before its block goes away
+            if (m->slot_used[slot]) (void) hipEventSynchronize(m->slot_done[slot]);
+            if (m->slot_buf[slot]) (void) hipFree(m->slot_buf[slot]);
+            m->slot_buf[slot] = nullptr; m->slot_cap[slot] = 0;
+            size_t cap = bytes < 65536 ? 65536 : bytes + bytes / 2;
+            if (hipMalloc((void **) &m->slot_buf[slot], cap) != hipSuccess) return;
+            m->slot_cap[slot] = cap;
+        } else if (m->slot_used[slot]) {
+            (void) hipStreamWaitEvent(stream, m->slot_done[slot], 0);
+        }
+        buf = m->slot_buf[slot];
     }
-    const uint32_t k = m->next_slot++ % (HF_NUM_SLOTS / 2);
-    *slot = k;
-    if (m->slot_cap[k] < bytes) { // grow: the previous user must be done before its block goes away
-        if (m->slot_used[k]) (void) hipEventSynchronize(m->slot_done[k]);
-        if (m->slot_buf[k]) (void) hipFree(m->slot_buf[k]);
-        m->slot_buf[k] = nullptr; m->slot_cap[k] = 0;
-        size_t cap = bytes < 65536 ? 65536 : bytes + bytes / 2;
-        if (hipMalloc((void **) &m->slot_buf[k], cap) != hipSuccess) return nullptr;
-        m->slot_cap[k] = cap;
-    } else if (m->slot_used[k]) {
-        (void) hipStreamWaitEvent(stream, m->slot_done[k], 0);
+    ~slot_lease() {
+        if (!buf || slot >= HF_NUM_SLOTS / 2) return; // nothing launched, or a captured launch
+        (void) hipEventRecord(m->slot_done[slot], stream);
+        m->slot_used[slot] = true;
     }
-    return m->slot_buf[k];
-}
-static void slot_release(const hf_field *hf, hipStream_t stream, uint32_t slot) {
-    hf_field *m = const_cast<hf_field *>(hf);
-    std::lock_guard<std::mutex> lock(*m->slot_mutex);
-    if (slot >= HF_NUM_SLOTS / 2) return; // a captured launch
-    (void) hipEventRecord(m->slot_done[slot], stream);
-    m->slot_used[slot] = true;
-}
+};
 
 static thread_local char g_err[512] = "no error";
 
@@ -245,6 +265,13 @@ extern "C" int hf_destroy(hf_field_t *hf) {
     return HF_OK;
 }
 
+extern "C" int hf_capture_reset(hf_field_t *hf) {
+    if (!hf) return fail(HF_EINVAL, "hf_capture_reset: NULL handle");
+    std::lock_guard<std::mutex> lock(*hf->slot_mutex);
+    hf->next_capture_slot = 0;
+    return HF_OK;
+}
+
 extern "C" int hf_set_heights(hf_field_t *hf, const float *d_heights, hf_stream_t stream) {
     if (!hf || !d_heights) return fail(HF_EINVAL, "hf_set_heights: NULL argument");
     hf_device_guard guard(hf->device);
@@ -388,11 +415,9 @@ extern "C" int hf_ray_intersect_preliminary(const hf_field_t *hf, size_t n, cons
     if (rc) return rc;
     if (!out || (n && !out->t)) return fail(HF_EINVAL, "hf_ray_intersect_preliminary: NULL output");
     {
-        uint32_t slot;
-        void *counter = slot_acquire(hf, (hipStream_t) stream, hf_trace_scratch_bytes(n), &slot);
-        if (!counter) return fail(HF_ENOMEM, "trace launch: scratch allocation failed");
-        hf_launch_trace(0, hf->dev, n, rays, active, out, nullptr, nullptr, 0, counter, (hipStream_t) stream);
-        slot_release(hf, (hipStream_t) stream, slot);
+        slot_lease lease(hf, (hipStream_t) stream, hf_trace_scratch_bytes(n));
+        if (!lease.buf) return fail(lease.code, "trace launch: %s", lease.why);
+        hf_launch_trace(0, hf->dev, n, rays, active, out, nullptr, nullptr, 0, lease.buf, (hipStream_t) stream);
     }
     HF_HIP(hipGetLastError());
     return HF_OK;
@@ -404,11 +429,9 @@ extern "C" int hf_ray_test(const hf_field_t *hf, size_t n, const hf_rays_t *rays
     if (rc) return rc;
     if (n && !out_hit) return fail(HF_EINVAL, "hf_ray_test: NULL output");
     {
-        uint32_t slot;
-        void *counter = slot_acquire(hf, (hipStream_t) stream, hf_trace_scratch_bytes(n), &slot);
-        if (!counter) return fail(HF_ENOMEM, "trace launch: scratch allocation failed");
-        hf_launch_trace(1, hf->dev, n, rays, active, nullptr, out_hit, nullptr, 0, counter, (hipStream_t) stream);
-        slot_release(hf, (hipStream_t) stream, slot);
+        slot_lease lease(hf, (hipStream_t) stream, hf_trace_scratch_bytes(n));
+        if (!lease.buf) return fail(lease.code, "trace launch: %s", lease.why);
+        hf_launch_trace(1, hf->dev, n, rays, active, nullptr, out_hit, nullptr, 0, lease.buf, (hipStream_t) stream);
     }
     HF_HIP(hipGetLastError());
     return HF_OK;
@@ -435,11 +458,9 @@ extern "C" int hf_ray_intersect(const hf_field_t *hf, size_t n, const hf_rays_t 
     if ((rc = check_flags("hf_ray_intersect", ray_flags))) return rc;
     if (!out_si) return fail(HF_EINVAL, "hf_ray_intersect: NULL output");
     {
-        uint32_t slot;
-        void *counter = slot_acquire(hf, (hipStream_t) stream, hf_trace_scratch_bytes(n), &slot);
-        if (!counter) return fail(HF_ENOMEM, "trace launch: scratch allocation failed");
-        hf_launch_trace(2, hf->dev, n, rays, active, out_pi, nullptr, out_si, ray_flags, counter, (hipStream_t) stream);
-        slot_release(hf, (hipStream_t) stream, slot);
+        slot_lease lease(hf, (hipStream_t) stream, hf_trace_scratch_bytes(n));
+        if (!lease.buf) return fail(lease.code, "trace launch: %s", lease.why);
+        hf_launch_trace(2, hf->dev, n, rays, active, out_pi, nullptr, out_si, ray_flags, lease.buf, (hipStream_t) stream);
     }
     HF_HIP(hipGetLastError());
     return HF_OK;
@@ -659,12 +680,10 @@ extern "C" int hf_reparam_trace(const hf_field_t *hf, size_t n, const float *con
     hf_reparam_args a = {};
     a.k = k; a.seed = seed; a.kappa = kappa; a.antithetic = antithetic;
     {
-        uint32_t slot;
-        void *counter = slot_acquire(hf, (hipStream_t) stream, hf_trace_scratch_bytes(n), &slot);
-        if (!counter) return fail(HF_ENOMEM, "trace launch: scratch allocation failed");
+        slot_lease lease(hf, (hipStream_t) stream, hf_trace_scratch_bytes(n));
+        if (!lease.buf) return fail(lease.code, "trace launch: %s", lease.why);
         hf_launch_trace(2, hf->dev, n, &rays, active, out_pi, nullptr, out_si,
-                        HF_RAY_ALL | HF_RAY_FOLLOWSHAPE | HF_RAY_BOUNDARYTEST, counter, (hipStream_t) stream, &a);
-        slot_release(hf, (hipStream_t) stream, slot);
+                        HF_RAY_ALL | HF_RAY_FOLLOWSHAPE | HF_RAY_BOUNDARYTEST, lease.buf, (hipStream_t) stream, &a);
     }
     HF_HIP(hipGetLastError());
     return HF_OK;
@@ -769,12 +788,10 @@ int packet_trace(const char *fn, int mode, const hf_field_t *hf, uint32_t n, con
     pi.t = d32 + 7 * HF_PACKET_MAX; pi.prim_uv[0] = d32 + 8 * HF_PACKET_MAX; pi.prim_uv[1] = d32 + 9 * HF_PACKET_MAX;
     pi.prim_index = (uint32_t *) (d32 + 10 * HF_PACKET_MAX);
     {
-        uint32_t slot;
-        void *counter = slot_acquire(hf, st->stream, hf_trace_scratch_bytes(n), &slot);
-        if (!counter) return fail(HF_ENOMEM, "%s: scratch allocation failed", fn);
+        slot_lease lease(hf, st->stream, hf_trace_scratch_bytes(n));
+        if (!lease.buf) return fail(lease.code, "%s: %s", fn, lease.why);
         hf_launch_trace(mode, hf->dev, n, &rays, dmask, mode == 0 ? &pi : nullptr, mode == 1 ? dhit : nullptr, nullptr, 0,
-                        counter, st->stream);
-        slot_release(hf, st->stream, slot);
+                        lease.buf, st->stream);
     }
     HF_HIP(hipGetLastError());
     HF_HIP(hipMemcpyAsync(st->h, st->d, PK_BYTES, hipMemcpyDeviceToHost, st->stream));

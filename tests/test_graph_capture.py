@@ -77,3 +77,74 @@ def test_one_step_captured_and_replayed_equals_eager(hf):
     print(f"per step: eager {1e6 * eager_s:.0f} us, graph replay {1e6 * graph_s:.0f} us")
     # eager launches after the capture still work (separate halves of the scratch ring)
     step(torch.cuda.current_stream(dev).cuda_stream); torch.cuda.synchronize()
+
+
+def test_capture_ring_refuses_the_33rd_captured_launch_and_reset_returns_the_blocks(hf):
+    """Every captured trace launch keeps its scratch block for the replays: the 33rd on one handle is refused with
+    HF_EINVAL (it would share work counters with the first), hf_capture_reset hands the blocks back (hf.h, HIP graphs)."""
+    from hf_amd import _capi
+    torch, dev, shape, st, hd, step, reset, keep = _setup(hf)
+    rays, r_s, pi_s, si_s, g_s = keep
+    lib = _capi.lib()
+    R = rays.shape[1]
+    _capi.check(lib.hf_capture_reset(shape._h))
+    s = torch.cuda.Stream(dev)
+    s.wait_stream(torch.cuda.current_stream(dev))
+    g = torch.cuda.CUDAGraph()
+    rcs = []
+    with torch.cuda.graph(g, stream=s):
+        for _ in range(34):
+            rcs.append(lib.hf_ray_intersect_preliminary(shape._h, R, C.byref(r_s), None, C.byref(pi_s), s.cuda_stream))
+    assert rcs[:32] == [_capi.HF_OK] * 32
+    assert rcs[32] == _capi.HF_EINVAL and rcs[33] == _capi.HF_EINVAL
+    assert b"captured trace launches" in lib.hf_last_error_string()
+    st["t"].fill_(-1.0)
+    g.replay(); torch.cuda.synchronize()
+    ref = shape.ray_intersect_preliminary(hf.Ray3f(rays[0:3], rays[3:6], rays[6])).t
+    assert torch.equal(st["t"], ref)                       # the 32 captured launches replay correctly
+    del g
+    _capi.check(lib.hf_capture_reset(shape._h))
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g2, stream=s):
+        rc = lib.hf_ray_intersect_preliminary(shape._h, R, C.byref(r_s), None, C.byref(pi_s), s.cuda_stream)
+    assert rc == _capi.HF_OK
+    st["t"].fill_(-1.0)
+    g2.replay(); torch.cuda.synchronize()
+    assert torch.equal(st["t"], ref)
+
+
+def test_scratch_ring_under_48_threads(hf, oracle):
+    """more host threads than eager scratch slots (32).  Every thread traces its own small wavefronts on
+    its own stream, many times; each result must be the single-threaded one (a launch that lost its work counters to
+    another leaves rays untraced)."""
+    import threading
+    import numpy as np
+    torch, dev, shape, st, hd, step, reset, keep = _setup(hf)
+    reset()
+    nthreads, reps, n = 48, 40, 4096
+    rays_all = hf.workload.ortho_rays(64, 64, 48, dev, origin=(0.6, 0.35, 2.0), target=(0.0, 0.0, 0.25), scale=(0.9, 0.9, 1.0))
+    ref = shape.ray_intersect_preliminary(hf.Ray3f(rays_all[0:3], rays_all[3:6], rays_all[6]))
+    torch.cuda.synchronize()
+    errs = []
+
+    def work(k):
+        try:
+            s = torch.cuda.Stream(dev)
+            r = rays_all[:, k * n:(k + 1) * n].contiguous()
+            with torch.cuda.stream(s):
+                for _ in range(reps):
+                    pi = shape.ray_intersect_preliminary(hf.Ray3f(r[0:3], r[3:6], r[6]))
+                    hit = shape.ray_test(hf.Ray3f(r[0:3], r[3:6], r[6]))
+                s.synchronize()
+            if not (torch.equal(pi.t, ref.t[k * n:(k + 1) * n]) and torch.equal(pi.prim_index, ref.prim_index[k * n:(k + 1) * n])
+                    and torch.equal(hit, torch.isfinite(ref.t[k * n:(k + 1) * n]))):
+                errs.append(k)
+        except Exception as e:  # noqa: BLE001
+            errs.append((k, repr(e)))
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(nthreads)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs

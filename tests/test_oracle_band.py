@@ -10,11 +10,15 @@ include/mitsuba/render/kdtree.h:2424-2448).  The band intersector shares no mip,
      packets from up to 50 units away, grazing packets, random and secondary-like rays).
 The GPU twins (HIP == band on samples of configs[1], configs[3] and the bounce rays) are in tests/test_gpu_band.py.
 """
+import os
+
 import numpy as np
 import pytest
 
 import common
 from oracle import hf_oracle as O
+
+NT = os.cpu_count() or 1   # (explicit: an earlier test's nthreads=1 would otherwise stick to the OpenMP runtime)
 
 
 def _same(a, b):
@@ -42,8 +46,8 @@ def test_band_equals_full_brute_force(kind, W, H, tw):
     far[0:3] -= far[3:6] / np.linalg.norm(far[3:6], axis=0) * 50.0
     parts.append(far)
     r = common.to_world_rays(np.concatenate(parts, 1), to_world)
-    _same(f.ray_intersect_preliminary(r, band=True), f.ray_intersect_preliminary(r, naive=True))
-    assert np.array_equal(f.ray_test(r, band=True), f.ray_test(r, naive=True))
+    _same(f.ray_intersect_preliminary(r, band=True, nthreads=NT), f.ray_intersect_preliminary(r, naive=True, nthreads=NT))
+    assert np.array_equal(f.ray_test(r, band=True, nthreads=NT), f.ray_test(r, naive=True, nthreads=NT))
 
 
 def mixed_rays(rng, n, max_height):
@@ -77,9 +81,9 @@ def test_hierarchical_walk_equals_band_at_baseline_sizes(N, n):
     rng = np.random.default_rng(N)
     f = O.OracleField(baseline_heights(N), max_height=0.5)
     r = mixed_rays(rng, n, 0.5)
-    band = f.ray_intersect_preliminary(r, band=True)
-    _same(f.ray_intersect_preliminary(r), band)
-    assert np.array_equal(f.ray_test(r), np.isfinite(band[0]))
+    band = f.ray_intersect_preliminary(r, band=True, nthreads=NT)
+    _same(f.ray_intersect_preliminary(r, nthreads=NT), band)
+    assert np.array_equal(f.ray_test(r, nthreads=NT), np.isfinite(band[0]))
     assert np.isfinite(band[0]).sum() > n // 10     # the sample does exercise hits
 
 
@@ -89,4 +93,4 @@ def test_hierarchical_walk_equals_band_on_rough_terrain():
     N = 1024
     f = O.OracleField(rng.uniform(0, 1, (N, N)).astype(np.float32), max_height=0.05)
     r = mixed_rays(rng, 40000, 0.05)
-    _same(f.ray_intersect_preliminary(r), f.ray_intersect_preliminary(r, band=True))
+    _same(f.ray_intersect_preliminary(r, nthreads=NT), f.ray_intersect_preliminary(r, band=True, nthreads=NT))
