@@ -18,28 +18,20 @@
 // the children the *fat* ray segment [0,t_hi] overlaps; the children of a level-1 node are
 // cells, whose two triangles are then tested.  Pending children live in 4-bit-per-level mask
 // stacks held in registers.
-// The 64 rays of a coherent wave (primary rays: one pixel's samples) share the upper levels:
-// the nodes of level HF_SUBTREE_LEVEL their fat rays can touch are enumerated row by row, front to
-// back, from wave-wide extents (walk_rows), box-tested per lane and handed to the per-lane walk of
-// the lanes that overlap them; an incoherent wave hands the root to every lane.  The per-lane walk runs in converged rounds: lanes walk until they hold
-// candidate cells, and the two-triangle test runs for all of them together, one cell per lane per
-// round.  The visited set is a conservative superset of the cells the ray can hit; the
-// per-triangle test and the tie rule are order independent, so the result equals the brute force's.
+// The 64 rays of a coherent wave (primary rays: one pixel's samples) share the upper levels: the wave's rays are
+// bounded by a beam, the nodes of level HF_SUBTREE_LEVEL along the beam are enumerated front to back with the LANES
+// acting as node testers (one round trip for all boxes and records, parked in the wave's LDS), and the survivors are
+// box-tested per lane, their own record evaluated for all lanes at once and handed to the per-lane walk of the lanes
+// that have children to visit (walk_beam); an incoherent wave hands the root to every lane.  The per-lane walk runs
+// in converged rounds: lanes walk until they hold candidate cells, and the two-triangle test runs for all of them
+// together, one cell per lane per round.  The visited set is a conservative superset of the cells the ray can hit;
+// the per-triangle test and the tie rule are order independent, so the result equals the brute force's.
 #include "hf_device.h"
 #include "hf_launch.h"
 
 #define HF_BLOCK 256
-#ifndef HF_HOIST
-#define HF_HOIST 0
-#endif
-#ifndef HF_XCD_CHUNK
-#define HF_XCD_CHUNK 1u // consecutive grabs that go to the same XCD (power of two)
-#endif
-#ifndef HF_TWO_FRONT
-#define HF_TWO_FRONT 1
-#endif
 #ifndef HF_SUBTREE_LEVEL
-#define HF_SUBTREE_LEVEL 5 // the shared walk hands nodes of this level (32x32 cells) to the per-lane walk
+#define HF_SUBTREE_LEVEL 4 // the beam sweep hands nodes of this level (16x16 cells) to the per-lane walk (5: +2 %, 3: the beam is too often wider than four nodes)
 #endif
 
 // ---------------------------------------------------------------------------------
@@ -273,8 +265,18 @@ __device__ __forceinline__ uint32_t *wcnt_base() {
     return c[threadIdx.x >> 6];
 }
 #define WCOUNT(k) do { const uint64_t e_ = __ballot(true); if ((int) (threadIdx.x & 63u) == __builtin_ctzll(e_)) wcnt_base()[k]++; } while (0)
+// WLANES(k): adds the number of lanes that run the enclosing code (k = 7: low half word = visits, high = cell rounds)
+#define WLANES(k, sh) do { const uint64_t e_ = __ballot(true); if ((int) (threadIdx.x & 63u) == __builtin_ctzll(e_)) wcnt_base()[k] += (uint32_t) __builtin_popcountll(e_) << (sh); } while (0)
+__device__ __forceinline__ void wstats_reset() { if ((threadIdx.x & 63u) < 8u) wcnt_base()[threadIdx.x & 63u] = 0u; }
+// diagnostic build (scripts/wstats.py): the counters of this batch replace the hit record
+#define WSTATS_EXPORT(alive, best) do { if (alive) { const uint32_t *c = wcnt_base(); (best).hit = true; \
+        (best).t = (float) c[0] + 1024.f * (float) c[1] + 1048576.f * (float) c[2]; \
+        (best).u = (float) c[3] + 4096.f * (float) c[4]; (best).v = (float) c[5] + 4096.f * (float) c[6]; (best).prim = c[7]; } } while (0)
 #else
+#define WLANES(k, sh) do { } while (0)
+#define WSTATS_EXPORT(alive, best) do { } while (0)
 #define WCOUNT(k) do { } while (0)
+__device__ __forceinline__ void wstats_reset() { }
 #endif
 
 // per-ray traversal constants (order space, cell units, re-based at t = tin)
@@ -448,31 +450,36 @@ struct hf_src_global {
 // "while-while": each lane walks until it holds a block with candidate cells (or is done); when
 // every lane of the call has stopped, the candidate cells are triangle-tested together, one
 // cell per lane per round -- the expensive test runs with all waiting lanes active.
-struct hf_walk {
+// STK: the register stack of pending-children masks, 4 bits per level -- 64 bits for a walk from the root (the root of
+// a 2^15-cell grid is 15 levels up), 32 bits for the walk below a hand-off node (HF_SUBTREE_LEVEL - 1 <= 8 levels)
+template <typename STK>
+struct hf_walk_t {
     uint32_t X, Y, cur, pend; // node (X,Y) of level L, its order-space children still to visit; candidate cells
-    uint64_t stk;             // 4 bits per level: the ancestors' pending children (L0 can be the root of a 2^15-cell grid)
-    int L, pc0, pr0;          // level; actual lower-left cell of the 2x2 block the candidate cells belong to
+    STK stk;                  // 4 bits per level: the ancestors' pending children
+    int L;                    // level (1 while the lane holds candidate cells: they are the children of node (X,Y))
     bool fin;                 // subtree exhausted
 };
+typedef hf_walk_t<uint64_t> hf_walk;
+__device__ __forceinline__ uint32_t stk_ctz(uint64_t v) { return (uint32_t) __builtin_ctzll(v); }
+__device__ __forceinline__ uint32_t stk_ctz(uint32_t v) { return (uint32_t) __builtin_ctz(v); }
 // start one level above the subtree root: a virtual parent whose only pending child is the root
-__device__ __forceinline__ void walk_init(hf_walk &w, uint32_t X0, uint32_t Y0, int L0) {
+template <typename STK>
+__device__ __forceinline__ void walk_init(hf_walk_t<STK> &w, uint32_t X0, uint32_t Y0, int L0) {
     w.X = X0 >> 1; w.Y = Y0 >> 1; w.cur = 1u << ((X0 & 1u) | ((Y0 & 1u) << 1)); w.pend = 0u;
-    w.stk = 0ull; w.L = L0 + 1; w.pc0 = 0; w.pr0 = 0; w.fin = false;
+    w.stk = 0; w.L = L0 + 1; w.fin = false;
 }
 // start AT node (X0,Y0) of level L0 whose record the caller has already evaluated: cur0 = its order-space children to visit
-__device__ __forceinline__ void walk_init_at(hf_walk &w, uint32_t X0, uint32_t Y0, int L0, uint32_t cur0) {
-    w.X = X0; w.Y = Y0; w.cur = cur0; w.pend = 0u; w.stk = 0ull; w.L = L0; w.pc0 = 0; w.pr0 = 0; w.fin = false;
-}
-__device__ __forceinline__ void walk_idle(hf_walk &w) {
-    w.X = 0u; w.Y = 0u; w.cur = 0u; w.pend = 0u; w.stk = 0ull; w.L = 0; w.pc0 = 0; w.pr0 = 0; w.fin = true;
+template <typename STK>
+__device__ __forceinline__ void walk_init_at(hf_walk_t<STK> &w, uint32_t X0, uint32_t Y0, int L0, uint32_t cur0) {
+    w.X = X0; w.Y = Y0; w.cur = cur0; w.pend = 0u; w.stk = 0; w.L = L0; w.fin = false;
 }
 
 // One round of the walk for every lane of the call: walk until parked or done, then the parked blocks, then
 // the candidate cells.  Lanes with w.fin set do nothing.  Returns whether this lane recorded a hit.
-template <bool ANY, typename Src>
+template <bool ANY, typename Src, typename STK>
 __device__ __forceinline__ bool walk_round(const hf_dev_field &f, const Src &src, const hf_ray_state &rs,
                                            const hf_trav &r, bool fx, bool fy, uint32_t fxm, uint32_t fym,
-                                           float &thi, hf_hit &best, hf_walk &w) {
+                                           float &thi, hf_hit &best, hf_walk_t<STK> &w) {
     auto loadh = [&src](int i, int j) { return src.height(i, j); };
     bool hit_any = false;
     // ---- walk until this lane holds candidate cells or has exhausted the subtree ----
@@ -482,8 +489,8 @@ __device__ __forceinline__ bool walk_round(const hf_dev_field &f, const Src &src
             // Node exhausted: pop.  Every level between here and the nearest ancestor with pending children is
             // skipped at once (the masks are 4-bit fields of one register: count the empty ones); the virtual
             // parent of the subtree root holds no children, so an all-zero stack means the subtree is done.
-            if (w.stk == 0ull) { w.fin = true; break; }
-            const uint32_t z = (uint32_t) __builtin_ctzll(w.stk) >> 2;
+            if (w.stk == 0) { w.fin = true; break; }
+            const uint32_t z = stk_ctz(w.stk) >> 2;
             w.stk >>= 4u * z;
             w.cur = (uint32_t) w.stk & 15u; w.stk >>= 4;
             w.X >>= z + 1u; w.Y >>= z + 1u; w.L += (int) z + 1;
@@ -495,8 +502,8 @@ __device__ __forceinline__ bool walk_round(const hf_dev_field &f, const Src &src
         // the mask may predate a hit: re-check the child's entry against the current t_hi
         const float te = fmaxf(((float) cx * S - r.gxm) * r.idx, ((float) cy * S - r.gym) * r.idy);
         if (te > thi) continue;
-        WCOUNT(5);
-        w.stk = (w.stk << 4) | (uint64_t) w.cur;
+        WCOUNT(5); WLANES(7, 0);
+        w.stk = (w.stk << 4) | (STK) w.cur;
         w.X = cx; w.Y = cy; --w.L;
         // the four children of (X,Y,L): sheared bounds on the fine levels, min/max boxes above
         const float Sc = 0.5f * S;
@@ -519,7 +526,6 @@ __device__ __forceinline__ bool walk_round(const hf_dev_field &f, const Src &src
             // j = 2 jy + jx, tested in any order -- the result is order independent) and the lane stops walking
             // until the converged triangle rounds below have run
             w.pend = m;
-            w.pc0 = (int) (2u * ix); w.pr0 = (int) (2u * iy);
             w.cur = 0u;
         } else {
             w.cur = to_order(m, fx, fy);
@@ -530,9 +536,11 @@ __device__ __forceinline__ bool walk_round(const hf_dev_field &f, const Src &src
     while (__ballot(w.pend != 0u) != 0ull) {
         WCOUNT(6);
         if (w.pend != 0u) {
+            WLANES(7, 16);
             const int j = __builtin_ctz(w.pend);
             w.pend &= w.pend - 1u;
-            const int cxx = w.pc0 + (j & 1), cyy = w.pr0 + (j >> 1);
+            // (the lane's node (X,Y) is the level-1 node whose children the candidate cells are: actual cell = 2 * actual node + j)
+            const int cxx = (int) (2u * (w.X ^ (fxm >> 1))) + (j & 1), cyy = (int) (2u * (w.Y ^ (fym >> 1))) + (j >> 1);
             const float z00 = loadh(cyy, cxx) * f.s, z10 = loadh(cyy, cxx + 1) * f.s;
             const float z01 = loadh(cyy + 1, cxx) * f.s, z11 = loadh(cyy + 1, cxx + 1) * f.s;
             if (test_cell(f, cxx, cyy, z00, z10, z01, z11, rs.oo, rs.od, rs.maxt, best)) {
@@ -565,7 +573,7 @@ template <bool ANY, typename Src>
 __device__ __forceinline__ bool walk_subtree_from(const hf_dev_field &f, const Src &src, const hf_ray_state &rs,
                                                   const hf_trav &r, bool fx, bool fy, uint32_t fxm, uint32_t fym,
                                                   uint32_t X0, uint32_t Y0, int L0, uint32_t cur0, float &thi, hf_hit &best) {
-    hf_walk w;
+    hf_walk_t<uint32_t> w;
     walk_init_at(w, X0, Y0, L0, cur0);
     bool hit_any = false;
     do {
@@ -588,129 +596,208 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
 }
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) { return ~wave_min_u32(~v); }
 
-// Coherent wave, upper levels by ROW SWEEP: instead of descending the pyramid from the root (a chain of dependent
-// node fetches: fetch -> test four children -> ballots -> next fetch, 42 % of a traversing wave's time), the nodes
-// of the hand-off level HF_SUBTREE_LEVEL that any lane's fat ray can touch are enumerated geometrically -- row by
-// row of that level in order space (front to back: a monotone ray that visits (i,j) before (i',j') has j' > j, or
-// j' = j and i' > i), the row's node range from the lanes' x extents inside the row slab (wave min / max) -- and each
-// enumerated node is tested per lane against its (min z, max z) box with the same arithmetic child_mask uses.
-// The node addresses do not depend on fetched data, and one node costs one box test instead of a share of a
-// four-child visit per level.  The enumeration is a superset (slack below); the per-lane test decides.
+// wave-wide minimum / maximum of a float, result uniform (DPP within rows of 16, readlane across rows); every lane calls
+__device__ __forceinline__ float row_min_f32(float v) { // minimum over the lane's row of 16, in every lane of the row
+    float x = v;
+    x = fminf(x, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true)));  // quad_perm [1,0,3,2]
+    x = fminf(x, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true)));  // quad_perm [2,3,0,1]
+    x = fminf(x, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xF, 0xF, true))); // row_half_mirror
+    x = fminf(x, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x140, 0xF, 0xF, true))); // row_mirror
+    return x;
+}
+__device__ __forceinline__ float wave_min_f32(float v) {
+    const int xi = __builtin_bit_cast(int, row_min_f32(v));
+    const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 0)), b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 16));
+    const float c = __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 32)), d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 48));
+    return fminf(fminf(a, b), fminf(c, d));
+}
+__device__ __forceinline__ float wave_max_f32(float v) { return -wave_min_f32(-v); }
+// Sixteen wave-wide minima for the price of sixteen row reductions (DPP) and one pass through LDS: the first lane
+// of each row of 16 parks its row's sixteen minima (four 16-byte writes), lane q < 16 then combines the four rows of
+// quantity q.  `red` = 64 floats of the wave's own LDS.  Result: quantity q in lane q (other lanes: undefined).
+__device__ __forceinline__ float wave_min16(const float (&h)[16], uint32_t lane, float *red) {
+    float rm[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) rm[q] = row_min_f32(h[q]);
+    if ((lane & 15u) == 0u) {
+        float4 *dst = (float4 *) (red + (lane & 48u)); // row r -> red[16 r ..]
+        dst[0] = make_float4(rm[0], rm[1], rm[2], rm[3]); dst[1] = make_float4(rm[4], rm[5], rm[6], rm[7]);
+        dst[2] = make_float4(rm[8], rm[9], rm[10], rm[11]); dst[3] = make_float4(rm[12], rm[13], rm[14], rm[15]);
+    }
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t q = lane & 15u;
+    const float v = fminf(fminf(red[q], red[16 + q]), fminf(red[32 + q], red[48 + q]));
+    __builtin_amdgcn_wave_barrier();
+    return v;
+}
+
+// Coherent wave, upper levels by BEAM SWEEP.  The row sweep above pays per enumerated node: a uniform (scalar) load of
+// its box, whose latency nothing hides, a per-lane box test and a ballot -- 16.8 nodes per batch of which 4.2 are
+// entered, and 7.8 rows with two wave reductions each: a fifth of a traversing batch's instructions.  Here the
+// lanes of the wave act as NODE testers first: the wave's rays are bounded by a beam (wave-wide extrema of the
+// per-lane slab coefficients: any lane's parameter interval in a node lies inside the beam's, any lane's height
+// inside the beam's height range over it), 16 rows x 4 node slots of the hand-off level are assigned to the 64
+// lanes front to back, every lane loads ITS node's box and record in one round trip (addresses do not depend on
+// loaded data), tests the beam against the box and parks box + record in the wave's LDS table.  The nodes that
+// survive (a ballot: bit order = front-to-back order) are then taken one by one: box and record come back from
+// LDS at a uniform address, every lane tests its own fat ray against the box with the row sweep's arithmetic, the
+// node's record is evaluated for all lanes at once (the first visit of the hand-off, hoisted: a node the rays only
+// skim is dropped here), and the lanes with children to visit walk them.  The beam test only removes nodes that no
+// lane's own test would accept, so the visited set -- and the result -- is the row sweep's.
+#ifndef HF_BEAM_ROWS
+#define HF_BEAM_ROWS 16 // slabs per pass (x 4 node slots per slab = the 64 lanes; fewer: the upper lanes sit the enumeration out)
+#endif
+// The slabs are cut across the beam's MAJOR direction (rows of the level when the rays advance faster in y, columns
+// when faster in x), so that a slab holds few nodes whatever the view: at most four, or the sweep declines.
+// Front-to-back either way: a monotone ray that visits slab s before s' has s' > s, and inside a slab the cross
+// coordinate only grows.
+#define HF_BEAM_CAND (4 * HF_BEAM_ROWS)
+struct hf_beam_lds {
+    struct { float4 box, pl, q01, q23; } e[HF_BEAM_CAND]; // (min z, max z) and record of the pass's nodes
+    float hdr[16];               // the beam (wave-uniform), parked here between passes instead of in registers
+};
+enum { BM_ISN, BM_ISX, BM_ICN, BM_ICX, BM_AS, BM_BS, BM_AC, BM_BC, BM_GCLO, BM_GCHI, BM_DCN, BM_DCX, BM_ZLO, BM_ZHI, BM_DZN, BM_DZX };
+// Returns false when it gives up -- an axis-parallel ray in the wave, or a beam wider than four nodes (rays that fan
+// out over a long path) -- at the start or between two passes: the caller then lets every live lane walk from the
+// root with the t_hi and the best hit reached so far (re-testing a cell is harmless: the result is a minimum).
 template <bool ANY>
-__device__ __forceinline__ void walk_rows(const hf_dev_field &f, const hf_ray_state &rs, bool alive, bool fx, bool fy,
-                                          hf_hit &best) {
+__device__ __forceinline__ bool walk_beam(const hf_dev_field &f, const hf_ray_state &rs, bool alive, bool fx, bool fy,
+                                          hf_hit &best, float &thi, hf_beam_lds *lds) {
     const hf_trav &r = rs.r;
-    const int top = f.top;
-    const uint32_t kd = (uint32_t) (top - HF_SUBTREE_LEVEL), nn = 1u << kd; // depth of the hand-off level, nodes per side
+    // (opaque copies: everything derived from the lane number or the level count is loop-invariant for the kernel's
+    // persistent loop, and the compiler would compute it all at kernel entry and then spill it -- 30 registers)
+    int top = f.top;
+    asm volatile("" : "+s"(top));
+    uint32_t lane = threadIdx.x & 63u;
+    asm volatile("" : "+v"(lane));
+    const uint32_t kd = (uint32_t) (top - HF_SUBTREE_LEVEL), nn = 1u << kd;
     const float S = (float) (1u << HF_SUBTREE_LEVEL), iS = 1.0f / S, lim = (float) nn - 0.5f;
-    const float2 *__restrict__ lvl = f.mip + hf_depth_off((int) kd);
-    float thi = alive ? rs.thi : -1.f; // dead lanes overlap nothing
-    // (per-lane values that are cheap to form are recomputed where they are used rather than held in registers
-    // across the per-lane walks: the kernel runs at 80 VGPRs)
+    const float inf = __builtin_inff();
+    const float dxo = __builtin_fabsf(rs.od.x) * (0.5f * (float) (f.W - 1)), dyo = __builtin_fabsf(rs.od.y) * (0.5f * (float) (f.H - 1));
+    // slab axis s / cross axis c (wave-uniform choice from the first live lane; any choice is correct)
+    const int first = __builtin_ctzll(__ballot(alive));
+    const bool xm = __builtin_amdgcn_readlane((int) (dxo > dyo), first) != 0;
+    uint32_t smin, smax;
+    {
+        // ---- the beam: wave-wide extrema, all as minima (a maximum is the negated minimum of the negated value; dead
+        // lanes contribute +inf) ----
+        const float gsm = xm ? r.gxm : r.gym, gsp = xm ? r.gxp : r.gyp, ids = xm ? r.idx : r.idy, dso = xm ? dxo : dyo;
+        const float gcm = xm ? r.gym : r.gxm, gcp = xm ? r.gyp : r.gxp, idc = xm ? r.idy : r.idx, dco = xm ? dyo : dxo;
+        float h[16];
+        h[BM_ISN] = ids; h[BM_ISX] = -ids; h[BM_ICN] = idc; h[BM_ICX] = -idc;
+        h[BM_AS] = -(gsm * ids); h[BM_BS] = gsp * ids; h[BM_AC] = -(gcm * idc); h[BM_BC] = gcp * idc;
+        h[BM_GCLO] = gcp; h[BM_GCHI] = -gcm; h[BM_DCN] = dco; h[BM_DCX] = -dco;
+        h[BM_ZLO] = r.gz - r.mz; h[BM_ZHI] = -(r.gz + r.mz); h[BM_DZN] = r.dz; h[BM_DZX] = -r.dz;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) h[q] = alive ? h[q] : inf;
+        const float hv = wave_min16(h, lane, (float *) &lds->e[0]); // (the node table is not in use yet)
+        // an axis-parallel ray in the wave (1/d = inf): decline
+        const float isx = -__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hv), BM_ISX));
+        const float icx = -__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hv), BM_ICX));
+        if (!(isx < inf) || !(icx < inf)) return false;
+        if (lane < 16u) lds->hdr[lane] = hv;
+        // slabs the wave's rays can touch: [g - m, g + m + t_hi d] per lane, widened by the slack of this estimate
+        const float sa = gsp - 1e-3f, sb = __builtin_fmaf(thi, dso, gsm);
+        const float sb2 = sb + 1e-3f + 1e-6f * sb;
+        smin = wave_min_u32(alive ? (uint32_t) fminf(fmaxf(sa * iS, 0.f), lim) : 0xFFFFFFFFu);
+        smax = wave_max_u32(alive ? (uint32_t) fminf(fmaxf(sb2 * iS, 0.f), lim) : 0u);
+    }
     hf_src_global src;
     src.mip = f.mip; src.shear = f.shear; src.h = f.h; src.top = f.top; src.W = f.W;
     const uint32_t lfxm = rs.fx ? ((1u << top) - 1u) : 0u, lfym = rs.fy ? ((1u << top) - 1u) : 0u;
-#ifdef HF_TSTATS
-    long long tsub = 0;
-#endif
-#ifdef HF_WSTATS
-    if ((threadIdx.x & 63u) < 8u) wcnt_base()[threadIdx.x & 63u] = 0u;
-#endif
-    // rows the wave's rays can touch: [gy - m, gy + m + t_hi dy] per lane, widened by the slack of this estimate
-    uint32_t jmin, jmax;
-    {
-        const float dyo = __builtin_fabsf(rs.od.y) * (0.5f * (float) (f.H - 1)); // cells per unit t, order space
-        const float ya = r.gyp - 1e-3f, yb = __builtin_fmaf(thi, dyo, r.gym);
-        const float yb2 = yb + 1e-3f + 1e-6f * yb;
-        jmin = wave_min_u32(alive ? (uint32_t) fminf(fmaxf(ya * iS, 0.f), lim) : 0xFFFFFFFFu);
-        jmax = wave_max_u32(alive ? (uint32_t) fminf(fmaxf(yb2 * iS, 0.f), lim) : 0u);
-    }
-    for (uint32_t j = jmin; j <= jmax; ++j) { // wave-uniform
-        const float fY = (float) j * S;
-        // this lane's parameter interval inside the row slab (fat in y), clipped to [0, t_hi]; v_max / v_min drop
-        // the NaN of 0 * inf (axis-parallel ray exactly on a slab plane)
-        const float ty0 = (fY - r.gym) * r.idy, ty1 = (fY + S - r.gyp) * r.idy;
-        const float t0 = fmaxf(ty0, 0.f), t1 = fminf(ty1, thi);
-        const bool in_row = t0 <= t1;
-        if (__ballot(in_row) == 0ull) {
-            // nobody is inside this row; done when nobody can reach a later one either
-            if (__ballot(ty1 <= thi) == 0ull) break;
-            continue;
-        }
+    for (uint32_t sb0 = smin; sb0 <= smax; sb0 += HF_BEAM_ROWS) { // wave-uniform
         WCOUNT(0);
-        uint32_t imin, imax;
+        __builtin_amdgcn_wave_barrier();
+        // ---- this lane's node of the pass: slab sb0 + lane / 4, slot lane % 4 of the beam's node range in that slab ----
+        uint32_t nc; // the node's cross coordinate (its slab number follows from the lane)
+        bool cand = false;
         {
-            const float dxo = __builtin_fabsf(rs.od.x) * (0.5f * (float) (f.W - 1));
-            const float xa = __builtin_fmaf(t0, dxo, r.gxp) - 1e-3f, xb = __builtin_fmaf(t1, dxo, r.gxm);
-            const float xb2 = xb + 1e-3f + 1e-6f * xb;
-            imin = wave_min_u32(in_row ? (uint32_t) fminf(fmaxf(xa * iS, 0.f), lim) : 0xFFFFFFFFu);
-            imax = wave_max_u32(in_row ? (uint32_t) fminf(fmaxf(xb2 * iS, 0.f), lim) : 0u);
+            const float4 h0 = *(const float4 *) &lds->hdr[0], h1 = *(const float4 *) &lds->hdr[4];
+            const float4 h2 = *(const float4 *) &lds->hdr[8], h3 = *(const float4 *) &lds->hdr[12];
+            const float isn = h0.x, isx = -h0.y, icn = h0.z, icx = -h0.w, as = -h1.x, bs = h1.y, ac = -h1.z, bc = h1.w;
+            const float gclo = h2.x, gchi = -h2.y, dcn = h2.z, dcx = -h2.w, zlo = h3.x, zhi = -h3.y, dzn = h3.z, dzx = -h3.w;
+            const float T = wave_max_f32(thi);
+            const uint32_t sl = sb0 + (lane >> 2);
+            const float fS = (float) sl * S;
+            const float t0 = fmaxf(fS * isn - as, 0.f), t1 = fminf((fS + S) * isx - bs, T);
+            const float t0s = fmaxf(t0 - (1e-5f * t0 + 1e-5f), 0.f), t1s = t1 + (1e-5f * t1 + 1e-5f); // rounding of the beam's own arithmetic
+            const bool in_slab = (HF_BEAM_CAND >= 64 || lane < (uint32_t) HF_BEAM_CAND) & (sl <= smax) & (t0s <= t1s);
+            const float ca = __builtin_fmaf(t0s, dcn, gclo) - 1e-3f, cb = __builtin_fmaf(t1s, dcx, gchi);
+            const float cb2 = cb + 1e-3f + 1e-6f * cb;
+            const uint32_t c0 = (uint32_t) fminf(fmaxf(ca * iS, 0.f), lim), c1 = (uint32_t) fminf(fmaxf(cb2 * iS, 0.f), lim);
+            if (__ballot(in_slab && c1 - c0 > 3u) != 0ull) return false; // a beam wider than four nodes
+            const uint32_t cc = c0 + (lane & 3u);
+            const bool valid = in_slab & (cc <= c1);
+            const uint32_t i = xm ? sl : cc, j = xm ? cc : sl;
+            nc = cc;
+            if (valid) {
+                const uint32_t ai = fx ? nn - 1u - i : i, aj = fy ? nn - 1u - j : j;
+                const uint32_t node = (aj << kd) + ai;
+                const float2 box = (f.mip + hf_depth_off((int) kd))[node];
+                const float4 *rec = f.shear + ((size_t) (hf_depth_off((int) kd) - 1u) + node) * 3;
+                const float4 pl = rec[0], q01 = rec[1], q23 = rec[2];
+                const float fC = (float) cc * S;
+                float u0 = fmaxf(fmaxf(fS * isn - as, fC * icn - ac), 0.f), u1 = fminf(fminf((fS + S) * isx - bs, (fC + S) * icx - bc), T);
+                u0 = fmaxf(u0 - (1e-5f * u0 + 1e-5f), 0.f); u1 = u1 + (1e-5f * u1 + 1e-5f);
+                const float za = zlo + fminf(u0 * dzn, u1 * dzn), zb = zhi + fmaxf(u0 * dzx, u1 * dzx);
+                const float zs = 1e-5f * (__builtin_fabsf(za) + __builtin_fabsf(zb)) + 1e-30f;
+                cand = (u0 <= u1) & (za - zs <= box.y) & (zb + zs >= box.x);
+                if (cand) {
+                    lds->e[lane].box = make_float4(box.x, box.y, 0.f, 0.f);
+                    lds->e[lane].pl = pl; lds->e[lane].q01 = q01; lds->e[lane].q23 = q23;
+                }
+            }
         }
-        const uint32_t aj = fy ? nn - 1u - j : j;
-        // Any-hit mode: lowest point of this lane's fat ray inside the row slab -- a node whose maximum lies below it
-        // for every lane is skipped on one comparison (three quarters of the enumerated nodes are rejected for being
-        // below the rays).  ray_test 2.54 -> 2.45 ms; in the closest-hit modes the extra live register costs what the
-        // skipped tests save (closest hit +-0, fused +2 %), so they test every node in full.
-        const float zrow = (ANY && in_row) ? fminf(__builtin_fmaf(t0, r.dz, r.gz), __builtin_fmaf(t1, r.dz, r.gz)) - r.mz
-                                           : (ANY ? __builtin_inff() : 0.f);
-        for (uint32_t i = imin; i <= imax; ++i) { // wave-uniform
+        uint64_t cm = __ballot(cand);
+        __builtin_amdgcn_wave_barrier(); // the table is read below by every lane (same wave: LDS operations stay in order)
+        while (cm != 0ull) { // wave-uniform, front to back
+            const uint32_t k = (uint32_t) __builtin_ctzll(cm);
+            cm &= cm - 1ull;
             WCOUNT(1);
-            const uint32_t ai = fx ? nn - 1u - i : i;
-            const float2 box = lvl[(aj << kd) + ai]; // uniform address: one line, broadcast
-            if (ANY && __ballot(zrow <= box.y) == 0ull) continue;
-            const float fX = (float) i * S, fYi = (float) j * S;
-            const float xlo = (fX - r.gxm) * r.idx, xhi = (fX + S - r.gxp) * r.idx;
-            const float ylo = (fYi - r.gym) * r.idy, yhi = (fYi + S - r.gyp) * r.idy;
+            const uint32_t ck = (uint32_t) __builtin_amdgcn_readlane((int) nc, (int) k), sk = sb0 + (k >> 2);
+            const uint32_t ci = xm ? sk : ck, nodej = xm ? ck : sk;
+            const float4 cbox = lds->e[k].box; // uniform address: broadcast
+            // ---- per-lane test of the node's box with the row sweep's arithmetic ----
+            const float fXc = (float) ci * S, fYc = (float) nodej * S;
+            const float xlo = (fXc - r.gxm) * r.idx, xhi = (fXc + S - r.gxp) * r.idx;
+            const float ylo = (fYc - r.gym) * r.idy, yhi = (fYc + S - r.gyp) * r.idy;
             const float u0 = fmaxf(fmaxf(xlo, ylo), 0.f), u1 = fminf(fminf(xhi, yhi), thi);
             const float za = __builtin_fmaf(u0, r.dz, r.gz), zb = __builtin_fmaf(u1, r.dz, r.gz);
-            const bool mine = (u0 <= u1) & (fminf(za, zb) - r.mz <= box.y) & (fmaxf(za, zb) + r.mz >= box.x);
-            if (__ballot(mine) == 0ull) continue;
+            const bool mine = (u0 <= u1) & (fminf(za, zb) - r.mz <= cbox.y) & (fmaxf(za, zb) + r.mz >= cbox.x);
+            if (__ballot(mine) == 0ull) {
+                // nobody overlaps this node; done when nobody can reach its slab -- or any later one -- before its t_hi
+                const float tsk = ((float) sk * S - (xm ? r.gxm : r.gym)) * (xm ? r.idx : r.idy);
+                if (__ballot(tsk <= thi) == 0ull) return true;
+                continue;
+            }
             WCOUNT(2);
-#ifdef HF_TSTATS
-            const long long ts0 = clock64();
-#endif
-#if HF_HOIST
-            // The node's own record is evaluated HERE, for all lanes at once (uniform address: scalar loads), instead
-            // of as the first visit of the per-lane walk: a node the rays only skim -- its box overlaps, its children's
-            // sheared ranges do not -- is dropped without a hand-off, and every hand-off is one iteration shorter.
+            // the node's own record, for all lanes at once
             uint32_t cur0 = 0u;
             {
-                const float4 *rec = src.sheared(HF_SUBTREE_LEVEL, ai, aj);
-                const float4 pl = rec[0], q01 = rec[1], q23 = rec[2];
+                const float4 pl = lds->e[k].pl, q01 = lds->e[k].q01, q23 = lds->e[k].q23;
                 const float Sc = 0.5f * S;
                 float gz, dz, mz;
-                shear_line(f, rs, fx, fy, pl.x, pl.y, pl.z, pl.w, fX + Sc, fYi + Sc, gz, dz, mz);
+                shear_line(f, rs, fx, fy, pl.x, pl.y, pl.z, pl.w, fXc + Sc, fYc + Sc, gz, dz, mz);
                 hf_quad q;
                 q.lo[0] = q01.x; q.hi[0] = q01.y; q.lo[1] = q01.z; q.hi[1] = q01.w;
                 q.lo[2] = q23.x; q.hi[2] = q23.y; q.lo[3] = q23.z; q.hi[3] = q23.w;
-                const uint32_t m4 = child_mask(r, fx, fy, fX, fYi, Sc, q, gz, dz, mz, thi);
+                const uint32_t m4 = child_mask(r, fx, fy, fXc, fYc, Sc, q, gz, dz, mz, thi);
                 cur0 = mine ? to_order(m4, fx, fy) : 0u;
             }
             if (__ballot(cur0 != 0u) == 0ull) continue;
             WCOUNT(4);
             if (cur0 != 0u) {
-                const bool h = walk_subtree_from<ANY>(f, src, rs, r, rs.fx, rs.fy, lfxm, lfym, i, j, HF_SUBTREE_LEVEL, cur0, thi, best);
+                const bool h = walk_subtree_from<ANY>(f, src, rs, r, rs.fx, rs.fy, lfxm, lfym, ci, nodej, HF_SUBTREE_LEVEL, cur0, thi, best);
                 if (ANY && h) thi = -1.f;
             }
-#else
-            if (mine) {
-                const bool h = walk_subtree<ANY>(f, src, rs, r, rs.fx, rs.fy, lfxm, lfym, i, j, HF_SUBTREE_LEVEL, thi, best);
-                if (ANY && h) thi = -1.f;
-            }
-#endif
-#ifdef HF_TSTATS
-            tsub += clock64() - ts0;
-#endif
+            if (ANY && __ballot(thi >= 0.f) == 0ull) return true;
         }
-        if (ANY && __ballot(thi >= 0.f) == 0ull) break;
+        // done when nobody can reach the first slab of the next pass before its t_hi
+        const float gsm = xm ? r.gxm : r.gym, ids = xm ? r.idx : r.idy;
+        const float tsn = ((float) (sb0 + HF_BEAM_ROWS) * S - gsm) * ids;
+        if (__ballot(tsn <= thi) == 0ull) break;
     }
-#ifdef HF_TSTATS // diagnostic build (scripts/tstats.py): cycles spent in the per-lane walks of this batch
-    if (alive) { best.hit = true; best.u = (float) tsub; }
-#endif
-#ifdef HF_WSTATS
-    if (alive) { const uint32_t *c = wcnt_base(); best.hit = true; best.t = (float) c[0] + 1024.f * (float) c[1] + 1048576.f * (float) c[2];
-        best.u = (float) c[3] + 4096.f * (float) c[4]; best.v = (float) c[5] + 4096.f * (float) c[6]; }
-#endif
+    return true;
 }
 
 // ---------------------------------------------------------------------------------
@@ -811,7 +898,7 @@ __device__ __forceinline__ void miss_si(hf_si_rec &si, v3 d, uint32_t flags) {
 #define HF_TRACE_WAVES_FUSED 5 // ... of the fused mode: its surface-interaction tail needs ~100 registers (6 waves: 30 spills, slower)
 #endif
 #ifndef HF_TRACE_WAVES
-#define HF_TRACE_WAVES 6 // resident waves per SIMD = workgroups per CU of the traversal kernel (80 VGPRs)
+#define HF_TRACE_WAVES 5 // resident waves per SIMD = workgroups per CU of the traversal kernel (96 VGPRs; 6 waves = 80 VGPRs spill 40 of them since the beam sweep: closest hit 2.76 vs 2.29 ms)
 #endif
 #define HF_NUM_XCD 8u // work counters per launch, one per XCD (power of two)
 #define HF_COUNTER_STRIDE 16u // in counters: 128 bytes apart
@@ -904,6 +991,7 @@ template <int MODE, bool AUX = false>
 __global__ __launch_bounds__(HF_BLOCK, (MODE == 2 ? HF_TRACE_WAVES_FUSED : HF_TRACE_WAVES)) void hf_trace_kernel(hf_trace_args a) {
     const hf_dev_field &f = a.f;
     const unsigned lane = threadIdx.x & 63u;
+    __shared__ hf_beam_lds s_beam[HF_BLOCK / 64]; // per wave: the beam and box + record of the pass's nodes (walk_beam)
     // Work distribution: the wavefront is cut into grabs of `grab` consecutive rays; XCD x owns grabs x, x + 8, ...
     // and hands them out through its own counter (a single counter serves ~80 fetches/us, which capped the rays
     // that only stream at half the memory bandwidth; eight addresses are served in parallel).  A wave pulls from the
@@ -926,17 +1014,13 @@ __global__ __launch_bounds__(HF_BLOCK, (MODE == 2 ? HF_TRACE_WAVES_FUSED : HF_TR
         if (lane == 0) g = atomicAdd(counter + (size_t) xc * HF_COUNTER_STRIDE, 1ull);
         g = ((unsigned long long) (uint32_t) __builtin_amdgcn_readfirstlane((int) (g >> 32)) << 32) |
             (unsigned long long) (uint32_t) __builtin_amdgcn_readfirstlane((int) (g & 0xffffffffull));
-        const unsigned long long gg = ((g / HF_XCD_CHUNK) * HF_NUM_XCD + xc) * HF_XCD_CHUNK + (g % HF_XCD_CHUNK);
+        const unsigned long long gg = g * HF_NUM_XCD + xc;
         if (gg >= n_grabs) {
             if (++tried == HF_NUM_XCD) break;
             xc = (xc + 1u) & (HF_NUM_XCD - 1u);
             continue;
         }
-#if HF_TWO_FRONT
         const unsigned long long base = ((gg & 1ull) ? (n_grabs >> 1) - 1ull - (gg >> 1) : (n_grabs >> 1) + (gg >> 1)) * grab;
-#else
-        const unsigned long long base = gg * grab;
-#endif
         // the ray of the batch in flight: requested one batch ahead (see below)
         v3 o = mk3(0.f, 0.f, 0.f), d = o;
         float maxt = 0.f;
@@ -1003,16 +1087,19 @@ __global__ __launch_bounds__(HF_BLOCK, (MODE == 2 ? HF_TRACE_WAVES_FUSED : HF_TR
 #ifdef HF_TSTATS
                 const long long tb1 = clock64();
 #endif
-                if (coherent && f.top > HF_SUBTREE_LEVEL) {
-                    walk_rows<MODE == 1>(f, rs, alive, fx0, fy0, best);
-                } else if (alive) {
-                    // incoherent wave (or a grid smaller than one hand-off node): every live lane walks from the root
+                // (one root-walk site for both the incoherent wave and a coherent wave whose beam sweep gives up)
+                float thi = alive ? rs.thi : -1.f; // dead lanes overlap nothing
+                bool root = alive;
+                wstats_reset();
+                if (coherent && f.top > HF_SUBTREE_LEVEL)
+                    root = !walk_beam<MODE == 1>(f, rs, alive, fx0, fy0, best, thi, &s_beam[threadIdx.x >> 6]) && alive && thi >= 0.f;
+                if (root) {
                     hf_src_global src;
                     src.mip = f.mip; src.shear = f.shear; src.h = f.h; src.top = f.top; src.W = f.W;
                     const uint32_t lfxm = rs.fx ? ((1u << f.top) - 1u) : 0u, lfym = rs.fy ? ((1u << f.top) - 1u) : 0u;
-                    float thi = rs.thi;
                     (void) walk_subtree<MODE == 1>(f, src, rs, rs.r, rs.fx, rs.fy, lfxm, lfym, 0u, 0u, f.top, thi, best);
                 }
+                if (coherent && f.top > HF_SUBTREE_LEVEL) WSTATS_EXPORT(alive, best);
 #ifdef HF_TSTATS
                 if (alive) { best.t = (float) (clock64() - tb0); best.v = (float) (tb1 - tb0); }
 #endif
@@ -1223,13 +1310,32 @@ struct hf_grad_dev {
 __device__ __forceinline__ float ld(const float *p, size_t i) { return p ? p[i] : 0.f; }
 __device__ __forceinline__ v3 ld3(const float *const p[3], size_t i) { return mk3(ld(p[0], i), ld(p[1], i), ld(p[2], i)); }
 
-__global__ __launch_bounds__(HF_BLOCK, 5) void hf_adjoint_kernel(hf_dev_field f, size_t n, hf_rays_dev rays,
-                                                              hf_pi_cdev pi, const uint8_t *__restrict__ active,
-                                                              hf_grad_dev g, uint32_t flags,
-                                                              float *__restrict__ grad_h, float *go0, float *go1,
-                                                              float *go2, float *gd0, float *gd1, float *gd2) {
-    const bool follow = (flags & 0x80u) != 0, detach = (flags & 0x100u) != 0;
-    const bool tex = (flags & (0x2u | 0x4u)) != 0;
+// The one kernel argument.  ~45 pointers and the field by value do not fit the scalar register file: held across the
+// loop body they were spilled into vector-register lanes (108 SGPR spills, 342 v_readlane / v_writelane).  As in the
+// traversal kernel, everything is read from the kernarg segment where it is used (scalar loads that hit the constant
+// cache), and every array is addressed as (pointer + wave-uniform element offset)[lane].
+struct hf_adjoint_args {
+    hf_dev_field f;
+    size_t n;
+    hf_rays_dev rays;
+    hf_pi_cdev pi;
+    const uint8_t *active;
+    hf_grad_dev g;
+    uint32_t flags;
+    float *grad_h;
+    float *go[3], *gd[3];
+};
+typedef const __attribute__((address_space(4))) hf_adjoint_args *hf_adj_kargs;
+__device__ __forceinline__ hf_adj_kargs adj_kargs() {
+    hf_adj_kargs ka = (hf_adj_kargs) __builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ka)); // opaque: keeps the loads that follow where they are written
+    return ka;
+}
+// (row + ub)[lo], 0 for an absent row: scalar base + 32-bit lane offset
+__device__ __forceinline__ float ldu(const float *p, size_t ub, uint32_t lo) { return p ? (p + ub)[lo] : 0.f; }
+
+__global__ __launch_bounds__(HF_BLOCK, 5) void hf_adjoint_kernel(hf_adjoint_args a_) {
+    (void) a_;
     // Wave-level pre-reduction of the scatter: the hits of one wave (one pixel's samples for
     // primary rays) fall on a few dozen vertices, so their three contributions each are first
     // summed into a 32x32-texel LDS tile anchored near the wave's first hit (ds_add_f32) and the
@@ -1237,24 +1343,45 @@ __global__ __launch_bounds__(HF_BLOCK, 5) void hf_adjoint_kernel(hf_dev_field f,
     // instead of three per ray.  Contributions outside the tile go straight to global memory.
     __shared__ float s_acc[HF_BLOCK / 64][HF_ADJ_TILE * HF_ADJ_TILE];
     float *acc = s_acc[threadIdx.x >> 6];
-    const int lane = (int) (threadIdx.x & 63u);
-    for (int k = lane; k < HF_ADJ_TILE * HF_ADJ_TILE; k += 64) acc[k] = 0.f;
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint32_t k = lane; k < HF_ADJ_TILE * HF_ADJ_TILE; k += 64) acc[k] = 0.f;
     const size_t stride = (size_t) gridDim.x * HF_BLOCK;
-    const size_t n_round = (n + HF_BLOCK - 1) / HF_BLOCK * HF_BLOCK; // whole waves stay in the loop (ballots below)
-    for (size_t i_raw = (size_t) blockIdx.x * HF_BLOCK + threadIdx.x; i_raw < n_round; i_raw += stride) {
-        const bool valid = i_raw < n;
-        const size_t i = valid ? i_raw : n - 1;
-        const float t_in = pi.t[i];
-        const bool act = valid && (active ? (active[i] != 0) : true) && (t_in != __builtin_inff());
+    for (size_t ub = (size_t) blockIdx.x * HF_BLOCK + (threadIdx.x & ~63u);; ub += stride) { // whole waves stay in the loop (ballots below)
+        hf_adj_kargs ka = adj_kargs();
+        const size_t n = ka->n;
+        if (ub >= n) break; // wave-uniform
+        const size_t left = n - ub;
+        const bool valid = lane < left;
+        const uint32_t lo = valid ? lane : (uint32_t) (left - 1);
+        const float t_in = (ka->pi.t + ub)[lo];
+        const uint8_t *active = ka->active;
+        const bool act = valid && (active ? ((active + ub)[lo] != 0) : true) && (t_in != __builtin_inff());
+        const uint32_t flags = ka->flags;
+        const bool follow = (flags & 0x80u) != 0, detach = (flags & 0x100u) != 0;
+        const bool tex = (flags & (0x2u | 0x4u)) != 0;
         v3 go = mk3(0.f, 0.f, 0.f), gd = mk3(0.f, 0.f, 0.f);
         float gh[3] = { 0.f, 0.f, 0.f };
         int vr[3] = { 0, 0, 0 }, vc[3] = { 0, 0, 0 };
         bool scatter = false;
         if (act) {
-            const v3 o = mk3(rays.o[0][i], rays.o[1][i], rays.o[2][i]);
-            const v3 d = mk3(rays.d[0][i], rays.d[1][i], rays.d[2][i]);
-            const float b1 = pi.u[i], b2 = pi.v[i], b0 = 1.f - b1 - b2;
-            const uint32_t prim = pi.prim[i];
+            // ONE batch of requests for everything a hit needs that does not depend on other loads -- the ray, the
+            // rest of pi, the 18 upstream rows -- then the three heights behind prim_index: three dependent round
+            // trips per iteration (pi.t, this batch, the heights) where the loads used to trail the arithmetic (six).
+            const v3 o = mk3((ka->rays.o[0] + ub)[lo], (ka->rays.o[1] + ub)[lo], (ka->rays.o[2] + ub)[lo]);
+            const v3 d = mk3((ka->rays.d[0] + ub)[lo], (ka->rays.d[1] + ub)[lo], (ka->rays.d[2] + ub)[lo]);
+            const float b1 = (ka->pi.u + ub)[lo], b2 = (ka->pi.v + ub)[lo], b0 = 1.f - b1 - b2;
+            const uint32_t prim = (ka->pi.prim + ub)[lo];
+            const float gt = ldu(ka->g.t, ub, lo);
+            v3 gp = mk3(ldu(ka->g.p[0], ub, lo), ldu(ka->g.p[1], ub, lo), ldu(ka->g.p[2], ub, lo));
+            const v3 gn_a = mk3(ldu(ka->g.n[0], ub, lo), ldu(ka->g.n[1], ub, lo), ldu(ka->g.n[2], ub, lo));
+            const v3 gn_b = mk3(ldu(ka->g.sh_n[0], ub, lo), ldu(ka->g.sh_n[1], ub, lo), ldu(ka->g.sh_n[2], ub, lo));
+            const float guv0 = ldu(ka->g.uv[0], ub, lo), guv1 = ldu(ka->g.uv[1], ub, lo);
+            v3 gu_ = mk3(0.f, 0.f, 0.f), gv_ = gu_;
+            if (flags & 0x4u) {
+                gu_ = mk3(ldu(ka->g.dp_du[0], ub, lo), ldu(ka->g.dp_du[1], ub, lo), ldu(ka->g.dp_du[2], ub, lo));
+                gv_ = mk3(ldu(ka->g.dp_dv[0], ub, lo), ldu(ka->g.dp_dv[1], ub, lo), ldu(ka->g.dp_dv[2], ub, lo));
+            }
+            const hf_dev_field f = load_field(&ka->f);
             v3 P[3];
             float U[3], V[3];
             int vi[3], vj[3];
@@ -1265,8 +1392,6 @@ __global__ __launch_bounds__(HF_BLOCK, 5) void hf_adjoint_kernel(hf_dev_field f,
                              __builtin_fmaf(P[0].z, b0, __builtin_fmaf(P[1].z, b1, P[2].z * b2)));
             const v3 z3 = mk3(0.f, 0.f, 0.f);
             v3 gP0 = z3, gP1 = z3, gP2 = z3, gdp0 = z3, gdp1 = z3;
-            v3 gp = ld3(g.p, i);
-            const float gt = ld(g.t, i);
 
             // dp_du / dp_dv from the (constant) texcoord differences
             if (flags & 0x4u) {
@@ -1274,7 +1399,6 @@ __global__ __launch_bounds__(HF_BLOCK, 5) void hf_adjoint_kernel(hf_dev_field f,
                 const float det = __builtin_fmaf(du0, dv1, -(dv0 * du1));
                 const float inv_det = rcp_ieee(det);
                 if (det != 0.f) {
-                    const v3 gu_ = ld3(g.dp_du, i), gv_ = ld3(g.dp_dv, i);
                     axpy3(dv1 * inv_det, gu_, gdp0);
                     axpy3(-dv0 * inv_det, gu_, gdp1);
                     axpy3(-du1 * inv_det, gv_, gdp0);
@@ -1287,8 +1411,7 @@ __global__ __launch_bounds__(HF_BLOCK, 5) void hf_adjoint_kernel(hf_dev_field f,
                 const float r = rsqrt_ieee(dot3(N, N));
                 const v3 nn = N * r;
                 const float sgn = f.flip ? -1.f : 1.f;
-                const v3 a = ld3(g.n, i), b = ld3(g.sh_n, i);
-                const v3 gn = mk3(sgn * (a.x + b.x), sgn * (a.y + b.y), sgn * (a.z + b.z));
+                const v3 gn = mk3(sgn * (gn_a.x + gn_b.x), sgn * (gn_a.y + gn_b.y), sgn * (gn_a.z + gn_b.z));
                 const float proj = dot3(nn, gn);
                 const v3 gN = mk3((gn.x - nn.x * proj) * r, (gn.y - nn.y * proj) * r, (gn.z - nn.z * proj) * r);
                 axpy3(1.f, cross3(dp1, gN), gdp0);
@@ -1304,7 +1427,6 @@ __global__ __launch_bounds__(HF_BLOCK, 5) void hf_adjoint_kernel(hf_dev_field f,
                 axpy3(-gt * tt / dd, d, gd);
             }
             // p = sum b_k P_k, uv = sum b_k uv_k
-            const float guv0 = ld(g.uv[0], i), guv1 = ld(g.uv[1], i);
             float gb0 = dot3(gp, P[0]), gb1 = dot3(gp, P[1]), gb2 = dot3(gp, P[2]);
             if (tex) {
                 gb0 += guv0 * U[0] + guv1 * V[0];
@@ -1341,7 +1463,7 @@ __global__ __launch_bounds__(HF_BLOCK, 5) void hf_adjoint_kernel(hf_dev_field f,
             axpy3(1.f, gdp0, gP1); axpy3(-1.f, gdp0, gP0);
             axpy3(1.f, gdp1, gP2); axpy3(-1.f, gdp1, gP0);
 
-            if (!detach && grad_h) { // dP_k/dh_k = s * (third column of to_world)
+            if (!detach && ka->grad_h) { // dP_k/dh_k = s * (third column of to_world)
                 const v3 ez = mk3(f.to_world[2], f.to_world[6], f.to_world[10]);
                 gh[0] = f.s * dot3(ez, gP0); gh[1] = f.s * dot3(ez, gP1); gh[2] = f.s * dot3(ez, gP2);
                 vr[0] = vi[0]; vr[1] = vi[1]; vr[2] = vi[2];
@@ -1351,6 +1473,8 @@ __global__ __launch_bounds__(HF_BLOCK, 5) void hf_adjoint_kernel(hf_dev_field f,
         }
         const uint64_t sm = __ballot(scatter);
         if (sm != 0ull) {
+            float *grad_h = adj_kargs()->grad_h;
+            const int W = adj_kargs()->f.W;
             // tile anchor from the first scattering lane (wave-uniform)
             const int src = __builtin_ctzll(sm);
             const int ar = __shfl(vr[0], src) - HF_ADJ_TILE / 4, ac = __shfl(vc[0], src) - HF_ADJ_TILE / 4;
@@ -1363,7 +1487,7 @@ __global__ __launch_bounds__(HF_BLOCK, 5) void hf_adjoint_kernel(hf_dev_field f,
                         atomicAdd(acc + rr * HF_ADJ_TILE + cc, gh[k]);
                         rows |= 1u << rr;
                     } else {
-                        atomicAdd(grad_h + (size_t) vr[k] * f.W + vc[k], gh[k]);
+                        atomicAdd(grad_h + (size_t) vr[k] * W + vc[k], gh[k]);
                     }
                 }
             }
@@ -1373,18 +1497,19 @@ __global__ __launch_bounds__(HF_BLOCK, 5) void hf_adjoint_kernel(hf_dev_field f,
             while (rows != 0u) { // wave-uniform
                 const int k2 = __builtin_ctz(rows) >> 1;
                 rows &= ~(3u << (2 * k2));
-                const int k = k2 * 64 + lane;
+                const int k = k2 * 64 + (int) lane;
                 const float v = acc[k];
                 if (v != 0.f) {
                     const int rr = ar + k / HF_ADJ_TILE, cc = ac + k % HF_ADJ_TILE;
-                    atomicAdd(grad_h + (size_t) rr * f.W + cc, v);
+                    atomicAdd(grad_h + (size_t) rr * W + cc, v);
                     acc[k] = 0.f;
                 }
             }
         }
         if (valid) {
-            if (go0) { go0[i] = go.x; go1[i] = go.y; go2[i] = go.z; }
-            if (gd0) { gd0[i] = gd.x; gd1[i] = gd.y; gd2[i] = gd.z; }
+            hf_adj_kargs kb = adj_kargs();
+            if (kb->go[0]) { (kb->go[0] + ub)[lo] = go.x; (kb->go[1] + ub)[lo] = go.y; (kb->go[2] + ub)[lo] = go.z; }
+            if (kb->gd[0]) { (kb->gd[0] + ub)[lo] = gd.x; (kb->gd[1] + ub)[lo] = gd.y; (kb->gd[2] + ub)[lo] = gd.z; }
         }
     }
 }
@@ -1401,10 +1526,10 @@ void hf_launch_adjoint(const hf_dev_field &f, size_t n, const hf_rays_t *rays, c
         g.dp_du[k] = gs->dp_du[k]; g.dp_dv[k] = gs->dp_dv[k];
     }
     g.uv[0] = gs->uv[0]; g.uv[1] = gs->uv[1];
-    hipLaunchKernelGGL(hf_adjoint_kernel, dim3(grid_for(n)), dim3(HF_BLOCK), 0, stream, f, n, to_dev(rays), p, active,
-                       g, flags, grad_h, grad_o ? grad_o[0] : nullptr, grad_o ? grad_o[1] : nullptr,
-                       grad_o ? grad_o[2] : nullptr, grad_d ? grad_d[0] : nullptr, grad_d ? grad_d[1] : nullptr,
-                       grad_d ? grad_d[2] : nullptr);
+    hf_adjoint_args a;
+    a.f = f; a.n = n; a.rays = to_dev(rays); a.pi = p; a.active = active; a.g = g; a.flags = flags; a.grad_h = grad_h;
+    for (int k = 0; k < 3; ++k) { a.go[k] = grad_o ? grad_o[k] : nullptr; a.gd[k] = grad_d ? grad_d[k] : nullptr; }
+    hipLaunchKernelGGL(hf_adjoint_kernel, dim3(grid_for(n)), dim3(HF_BLOCK), 0, stream, a);
 }
 
 // ---------------------------------------------------------------------------------

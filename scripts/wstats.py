@@ -15,9 +15,11 @@ z = torch.zeros(1, device=dev, dtype=torch.float64)
 u = torch.where(trav, pi.prim_uv[0].double().reshape(-1, 64), z).max(1).values
 v = torch.where(trav, pi.prim_uv[1].double().reshape(-1, 64), z).max(1).values
 t = torch.where(trav, pi.t.double().reshape(-1, 64), z).max(1).values
+pr = torch.where(trav, pi.prim_index.to(torch.int64).reshape(-1, 64) & 0xFFFFFFFF, torch.zeros(1, device=dev, dtype=torch.int64)).max(1).values
 w = trav.any(1)
-u, v, t = u[w], v[w], t[w]
+u, v, t, pr = u[w], v[w], t[w], pr[w]
 def m(x): return float(x.mean())
 print(f"batches {int(w.sum())}")
 print(f"row sweep: rows with a lane inside {m(t % 1024):.1f}, nodes box-tested {m(torch.floor(t / 1024) % 1024):.1f}, hand-offs with work {m(torch.floor(t / 1048576)):.1f}")
 print(f"subtree (max over lanes of per-call sums; lanes run the same wave-level loop): iterations {m(u % 4096):.1f}, hand-offs after the hoisted visit (HF_HOIST builds) {m(torch.floor(u / 4096)):.1f}, visits {m(v % 4096):.1f}, cell rounds {m(torch.floor(v / 4096)):.1f}")
+print(f"lanes per visit {float((pr & 0xFFFF).double().mean()) / max(m(v % 4096), 1e-9):.1f}, lanes per cell round {float((pr >> 16).double().mean()) / max(m(torch.floor(v / 4096)), 1e-9):.1f}")
