@@ -67,8 +67,9 @@ __device__ __forceinline__ v3 xform_vec(const float *m, v3 v) {
 // Quadtree over 2^top x 2^top cells (top >= 1; cells beyond the grid do not exist).
 // A node of level l covers 2^l x 2^l cells.  Levels 1..top are stored COARSE-FIRST in one
 // padded array: depth k = top - l holds 2^k x 2^k nodes, row-major with pitch 2^k, at
-// offset (4^k - 1)/3 + 1 (entry 0 is padding, the root is entry 1; the first 1366 entries --
-// depths 0..5 -- are what the traversal kernels stage in LDS).  Node (ix,iy) of level l holds
+// offset (4^k - 1)/3 + 1 (entry 0 is padding, the root is entry 1: the global range that bbox and the slab clip
+// read; the beam sweep of the traversal kernel reads one depth of it, the level of its hand-off nodes, and parks
+// the entries of the nodes along the beam in LDS).  Node (ix,iy) of level l holds
 // (min z, max z) over the vertices of its existing cells; nodes without any existing cell hold
 // (+inf, -inf) and fail every overlap test.
 struct hf_dev_field {

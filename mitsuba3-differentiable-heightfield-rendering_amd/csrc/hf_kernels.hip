@@ -860,31 +860,6 @@ struct hf_si_dev {
 __device__ __forceinline__ void st(float *p, size_t ub, uint32_t lo, float v) { if (p) __builtin_nontemporal_store(v, &(p + ub)[lo]); }
 #define st3(p, ub, lo, v) do { st((p)[0], ub, lo, (v).x); st((p)[1], ub, lo, (v).y); st((p)[2], ub, lo, (v).z); } while (0)
 
-template <typename SiDev>
-__device__ __forceinline__ void store_si(const SiDev &out, size_t ub, uint32_t lo, const hf_si_rec &si, uint32_t flags) {
-    st(out.t, ub, lo, si.t);
-    st3(out.p, ub, lo, si.p);
-    st3(out.n, ub, lo, si.n);
-    st(out.uv[0], ub, lo, si.uv0); st(out.uv[1], ub, lo, si.uv1);
-    st3(out.sh_n, ub, lo, si.sh_n);
-    st3(out.dp_du, ub, lo, si.dp_du);
-    st3(out.dp_dv, ub, lo, si.dp_dv);
-    if (flags & 0x40u) st(out.bt, ub, lo, si.boundary_test);
-    st3(out.sh_s, ub, lo, si.sh_s);
-    st3(out.sh_t, ub, lo, si.sh_t);
-    st3(out.wi, ub, lo, si.wi);
-}
-
-// zero-initialised record for inactive / missed lanes (interaction.h:479-499, 667-673)
-__device__ __forceinline__ void miss_si(hf_si_rec &si, v3 d, uint32_t flags) {
-    const v3 z = mk3(0.f, 0.f, 0.f);
-    si.t = __builtin_inff();
-    si.p = z; si.n = z; si.uv0 = 0.f; si.uv1 = 0.f; si.sh_n = z; si.dp_du = z; si.dp_dv = z;
-    si.boundary_test = (flags & 0x40u) ? 1e8f : 0.f;
-    si.sh_s = z; si.sh_t = z;
-    si.wi = neg3(d);
-}
-
 #define HF_GRAB 256 // most rays a wave takes from the work counter per fetch (hf_grab_for); 512 before the per-XCD counters
 // Scratch block of one trace launch (zeroed by hf_launch_trace): the per-XCD work counters.
 #define HF_SCR_BYTES 1024
@@ -1235,28 +1210,80 @@ struct hf_pi_cdev {
     const uint32_t *prim;
 };
 
-__global__ __launch_bounds__(HF_BLOCK) void hf_si_kernel(hf_dev_field f, size_t n, hf_rays_dev rays,
-                                                         hf_pi_cdev pi, const uint8_t *__restrict__ active,
-                                                         hf_si_dev sio, uint32_t flags) {
+// The one kernel argument, read from the kernarg segment where it is used (as in the traversal kernel: ~45 pointers and
+// the field by value held across the loop body were spilled into vector-register lanes: 134 SGPR spills).
+struct hf_si_args {
+    hf_dev_field f;
+    size_t n;
+    hf_rays_dev rays;
+    hf_pi_cdev pi;
+    const uint8_t *active;
+    hf_si_dev sio;
+    uint32_t flags;
+};
+// compute_si_to sink of hf_si_kernel: a field goes to memory when it is final, row pointers from the kernarg segment
+struct hf_si_kernel_sink {
+    const __attribute__((address_space(4))) hf_si_args *ka;
+    size_t ub;
+    uint32_t lo, flags;
+    __device__ __forceinline__ void s1(float *p, float v) { st(p, ub, lo, v); }
+    __device__ __forceinline__ void s3(float *p0, float *p1, float *p2, v3 v) { st(p0, ub, lo, v.x); st(p1, ub, lo, v.y); st(p2, ub, lo, v.z); }
+    __device__ __forceinline__ void t(float v) { s1(ka->sio.t, v); }
+    __device__ __forceinline__ void p(v3 v) { s3(ka->sio.p[0], ka->sio.p[1], ka->sio.p[2], v); }
+    __device__ __forceinline__ void boundary_test(float v) { if (flags & 0x40u) s1(ka->sio.bt, v); }
+    __device__ __forceinline__ void uv(float a, float b) { s1(ka->sio.uv[0], a); s1(ka->sio.uv[1], b); }
+    __device__ __forceinline__ void dp_du(v3 v) { s3(ka->sio.dp_du[0], ka->sio.dp_du[1], ka->sio.dp_du[2], v); }
+    __device__ __forceinline__ void dp_dv(v3 v) { s3(ka->sio.dp_dv[0], ka->sio.dp_dv[1], ka->sio.dp_dv[2], v); }
+    __device__ __forceinline__ void n(v3 v) {
+        s3(ka->sio.n[0], ka->sio.n[1], ka->sio.n[2], v);
+        s3(ka->sio.sh_n[0], ka->sio.sh_n[1], ka->sio.sh_n[2], v);
+    }
+    __device__ __forceinline__ void sh_s(v3 v) { s3(ka->sio.sh_s[0], ka->sio.sh_s[1], ka->sio.sh_s[2], v); }
+    __device__ __forceinline__ void sh_t(v3 v) { s3(ka->sio.sh_t[0], ka->sio.sh_t[1], ka->sio.sh_t[2], v); }
+    __device__ __forceinline__ void wi(v3 v) { s3(ka->sio.wi[0], ka->sio.wi[1], ka->sio.wi[2], v); }
+};
+
+__global__ __launch_bounds__(HF_BLOCK) void hf_si_kernel(hf_si_args a_) {
+    (void) a_;
+    const uint32_t lane = threadIdx.x & 63u;
     const size_t stride = (size_t) gridDim.x * HF_BLOCK;
-    for (size_t i = (size_t) blockIdx.x * HF_BLOCK + threadIdx.x; i < n; i += stride) {
-        const v3 o = mk3(rays.o[0][i], rays.o[1][i], rays.o[2][i]);
-        const v3 d = mk3(rays.d[0][i], rays.d[1][i], rays.d[2][i]);
-        const float t = pi.t[i];
-        const bool act = (active ? (active[i] != 0) : true) && (t != __builtin_inff());
-        hf_si_rec si;
-        if (act) compute_si(f, o, d, t, pi.u[i], pi.v[i], pi.prim[i], flags, si);
-        else     miss_si(si, d, flags);
-        store_si(sio, i, 0u, si, flags);
+    for (size_t ub = (size_t) blockIdx.x * HF_BLOCK + (threadIdx.x & ~63u);; ub += stride) {
+        const __attribute__((address_space(4))) hf_si_args *ka =
+            (const __attribute__((address_space(4))) hf_si_args *) __builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(ka)); // opaque: keeps the loads that follow where they are written
+        const size_t n = ka->n;
+        if (ub >= n) break; // wave-uniform
+        if (lane >= n - ub) continue;
+        const uint32_t lo = lane;
+        const v3 o = mk3((ka->rays.o[0] + ub)[lo], (ka->rays.o[1] + ub)[lo], (ka->rays.o[2] + ub)[lo]);
+        const v3 d = mk3((ka->rays.d[0] + ub)[lo], (ka->rays.d[1] + ub)[lo], (ka->rays.d[2] + ub)[lo]);
+        const float t = (ka->pi.t + ub)[lo];
+        const uint8_t *active = ka->active;
+        const bool act = (active ? ((active + ub)[lo] != 0) : true) && (t != __builtin_inff());
+        const uint32_t flags = ka->flags;
+        hf_si_kernel_sink out = { ka, ub, lo, flags };
+        if (act) {
+            const float b1 = (ka->pi.u + ub)[lo], b2 = (ka->pi.v + ub)[lo];
+            const uint32_t prim = (ka->pi.prim + ub)[lo];
+            const hf_dev_field f = load_field(&ka->f);
+            compute_si_to(f, o, d, t, b1, b2, prim, flags, out);
+        } else { // zero-initialised record (interaction.h:479-499, 667-673)
+            const v3 z = mk3(0.f, 0.f, 0.f);
+            out.t(__builtin_inff()); out.p(z); out.boundary_test((flags & 0x40u) ? 1e8f : 0.f);
+            out.uv(0.f, 0.f); out.dp_dv(z); out.n(z); out.dp_du(z); out.sh_s(z); out.sh_t(z);
+            out.wi(neg3(d));
+        }
     }
 }
 
 void hf_launch_si(const hf_dev_field &f, size_t n, const hf_rays_t *rays, const hf_pi_const_t *pi,
                   const uint8_t *active, const hf_si_t *si, uint32_t flags, hipStream_t stream) {
     if (n == 0) return;
-    const hf_pi_cdev p = { pi->t, pi->prim_uv[0], pi->prim_uv[1], pi->prim_index };
-    hipLaunchKernelGGL(hf_si_kernel, dim3(grid_for(n)), dim3(HF_BLOCK), 0, stream, f, n, to_dev(rays), p, active,
-                       to_dev(si), flags);
+    hf_si_args a;
+    a.f = f; a.n = n; a.rays = to_dev(rays);
+    a.pi.t = pi->t; a.pi.u = pi->prim_uv[0]; a.pi.v = pi->prim_uv[1]; a.pi.prim = pi->prim_index;
+    a.active = active; a.sio = to_dev(si); a.flags = flags;
+    hipLaunchKernelGGL(hf_si_kernel, dim3(grid_for(n)), dim3(HF_BLOCK), 0, stream, a);
 }
 
 // ---------------------------------------------------------------------------------
@@ -1334,6 +1361,8 @@ __device__ __forceinline__ hf_adj_kargs adj_kargs() {
 // (row + ub)[lo], 0 for an absent row: scalar base + 32-bit lane offset
 __device__ __forceinline__ float ldu(const float *p, size_t ub, uint32_t lo) { return p ? (p + ub)[lo] : 0.f; }
 
+// RAYGRAD: dL/do and dL/dd are wanted (hf_adjoint's grad_o / grad_d); without them their accumulation is dead code
+template <bool RAYGRAD>
 __global__ __launch_bounds__(HF_BLOCK, 5) void hf_adjoint_kernel(hf_adjoint_args a_) {
     (void) a_;
     // Wave-level pre-reduction of the scatter: the hits of one wave (one pixel's samples for
@@ -1506,7 +1535,7 @@ __global__ __launch_bounds__(HF_BLOCK, 5) void hf_adjoint_kernel(hf_adjoint_args
                 }
             }
         }
-        if (valid) {
+        if (RAYGRAD && valid) {
             hf_adj_kargs kb = adj_kargs();
             if (kb->go[0]) { (kb->go[0] + ub)[lo] = go.x; (kb->go[1] + ub)[lo] = go.y; (kb->go[2] + ub)[lo] = go.z; }
             if (kb->gd[0]) { (kb->gd[0] + ub)[lo] = gd.x; (kb->gd[1] + ub)[lo] = gd.y; (kb->gd[2] + ub)[lo] = gd.z; }
@@ -1529,7 +1558,8 @@ void hf_launch_adjoint(const hf_dev_field &f, size_t n, const hf_rays_t *rays, c
     hf_adjoint_args a;
     a.f = f; a.n = n; a.rays = to_dev(rays); a.pi = p; a.active = active; a.g = g; a.flags = flags; a.grad_h = grad_h;
     for (int k = 0; k < 3; ++k) { a.go[k] = grad_o ? grad_o[k] : nullptr; a.gd[k] = grad_d ? grad_d[k] : nullptr; }
-    hipLaunchKernelGGL(hf_adjoint_kernel, dim3(grid_for(n)), dim3(HF_BLOCK), 0, stream, a);
+    if (grad_o || grad_d) hipLaunchKernelGGL(hf_adjoint_kernel<true>, dim3(grid_for(n)), dim3(HF_BLOCK), 0, stream, a);
+    else                  hipLaunchKernelGGL(hf_adjoint_kernel<false>, dim3(grid_for(n)), dim3(HF_BLOCK), 0, stream, a);
 }
 
 // ---------------------------------------------------------------------------------
@@ -1558,36 +1588,48 @@ struct hf_reparam_bwd_args {
 #ifndef HF_RB_TILE
 #define HF_RB_TILE 64 // the auxiliary hits of a pixel spread over tens of cells: a larger tile than hf_adjoint_kernel's
 #endif
-__global__ __launch_bounds__(HF_BLOCK, (HF_RB_TILE > 32 ? 2 : 5)) void hf_reparam_backward_kernel(hf_dev_field f, hf_reparam_bwd_args a) {
+// (one argument struct, read from the kernarg segment where it is used: see hf_adjoint_kernel)
+struct hf_reparam_bwd_kargs {
+    hf_dev_field f;
+    hf_reparam_bwd_args a;
+};
+__global__ __launch_bounds__(HF_BLOCK, (HF_RB_TILE > 32 ? 2 : 5)) void hf_reparam_backward_kernel(hf_reparam_bwd_kargs k_) {
+    (void) k_;
+    typedef const __attribute__((address_space(4))) hf_reparam_bwd_kargs *kargs_t;
+    kargs_t kc = (kargs_t) __builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kc));
+    const size_t a_n = kc->a.n;
     __shared__ float s_acc[HF_BLOCK / 64][HF_RB_TILE * HF_RB_TILE]; // per-wave accumulation tile, as in hf_adjoint_kernel
     float *acc = s_acc[threadIdx.x >> 6];
     const int lane = (int) (threadIdx.x & 63u);
     for (int k = lane; k < HF_RB_TILE * HF_RB_TILE; k += 64) acc[k] = 0.f;
     hf_reparam_args sa = {}; // what the sampling helpers read
-    sa.seed = a.seed; sa.kappa = a.kappa; sa.exponent = a.exponent; sa.antithetic = a.antithetic;
+    sa.seed = kc->a.seed; sa.kappa = kc->a.kappa; sa.exponent = kc->a.exponent; sa.antithetic = kc->a.antithetic;
     const size_t stride = (size_t) gridDim.x * HF_BLOCK;
-    const size_t n_round = (a.n + HF_BLOCK - 1) / HF_BLOCK * HF_BLOCK; // whole waves stay in the loop (ballots below)
+    const size_t n_round = (a_n + HF_BLOCK - 1) / HF_BLOCK * HF_BLOCK; // whole waves stay in the loop (ballots below)
     for (size_t i_raw = (size_t) blockIdx.x * HF_BLOCK + threadIdx.x; i_raw < n_round; i_raw += stride) {
-        const bool valid = i_raw < a.n;
-        const size_t i = valid ? i_raw : a.n - 1;
-        const bool act = valid && (a.active ? (a.active[i] != 0) : true);
+        kargs_t ka = (kargs_t) __builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(ka)); // opaque: keeps the loads that follow inside the loop body
+        const bool valid = i_raw < a_n;
+        const size_t i = valid ? i_raw : a_n - 1;
+        const bool act = valid && (ka->a.active ? (ka->a.active[i] != 0) : true);
         uint32_t hm = 0u; // samples that hit
-        for (uint32_t k = 0; k < a.num_rays; ++k)
-            hm |= (act && a.pi_t[k * a.stride + i] != __builtin_inff()) ? (1u << k) : 0u;
+        for (uint32_t k = 0; k < ka->a.num_rays; ++k)
+            hm |= (act && ka->a.pi_t[k * ka->a.stride + i] != __builtin_inff()) ? (1u << k) : 0u;
         if (__ballot(hm != 0u) == 0ull) continue; // wave-uniform
         v3 o = mk3(0.f, 0.f, 0.f), d = o, gV = o;
         float gdivV = 0.f;
         if (hm != 0u) {
-            o = mk3(a.o[0][i], a.o[1][i], a.o[2][i]);
-            d = mk3(a.d[0][i], a.d[1][i], a.d[2][i]);
+            o = mk3(ka->a.o[0][i], ka->a.o[1][i], ka->a.o[2][i]);
+            d = mk3(ka->a.d[0][i], ka->a.d[1][i], ka->a.d[2][i]);
             // first loop: Z = sum_k w_k, dZ = sum_k d_w_omega_k, in sample order from zero
             float Zs = 0.f;
             v3 dZ = mk3(0.f, 0.f, 0.f);
-            for (uint32_t k = 0; k < a.num_rays; ++k) {
+            for (uint32_t k = 0; k < ka->a.num_rays; ++k) {
                 sa.k = k;
                 hf_aux_sample q;
                 aux_sample(sa, i, d, q);
-                const float B = ((hm >> k) & 1u) ? a.si_bt[k * a.stride + i] : 1.0f;
+                const float B = ((hm >> k) & 1u) ? ka->a.si_bt[k * ka->a.stride + i] : 1.0f;
                 float w;
                 v3 dw;
                 reparam_weight(sa, q, d, B, w, dw);
@@ -1596,8 +1638,8 @@ __global__ __launch_bounds__(HF_BLOCK, (HF_RB_TILE > 32 ? 2 : 5)) void hf_repara
             }
             // the part of reparam_grad_vdirect that is common to the samples of a ray
             const float Z = fmaxf(Zs, 1e-8f), iZ = 1.0f / Z;
-            const v3 gd = mk3(a.g_dir[0][i], a.g_dir[1][i], a.g_dir[2][i]);
-            const float gdiv = a.g_div[i];
+            const v3 gd = mk3(ka->a.g_dir[0][i], ka->a.g_dir[1][i], ka->a.g_dir[2][i]);
+            const float gdiv = ka->a.g_div[i];
             const float dd = dot3(d, d), idn = 1.0f / __builtin_sqrtf(dd);
             const float pr = dot3(d, gd) / dd;
             const float c = gdiv * iZ * iZ;
@@ -1611,7 +1653,7 @@ __global__ __launch_bounds__(HF_BLOCK, (HF_RB_TILE > 32 ? 2 : 5)) void hf_repara
         bool anchored = false;
         uint64_t rows = 0ull;
         const uint32_t hm_any = wave_or(hm);
-        for (uint32_t k = 0; k < a.num_rays; ++k) {
+        for (uint32_t k = 0; k < ka->a.num_rays; ++k) {
             if (((hm_any >> k) & 1u) == 0u) continue; // wave-uniform
             const bool hit = ((hm >> k) & 1u) != 0u;
             float gh[3] = { 0.f, 0.f, 0.f };
@@ -1622,15 +1664,15 @@ __global__ __launch_bounds__(HF_BLOCK, (HF_RB_TILE > 32 ? 2 : 5)) void hf_repara
                 aux_sample(sa, i, d, q);
                 float w;
                 v3 dw;
-                reparam_weight(sa, q, d, a.si_bt[k * a.stride + i], w, dw);
+                reparam_weight(sa, q, d, ka->a.si_bt[k * ka->a.stride + i], w, dw);
                 const v3 gVd = mk3(__builtin_fmaf(w, gV.x, gdivV * dw.x), __builtin_fmaf(w, gV.y, gdivV * dw.y),
                                    __builtin_fmaf(w, gV.z, gdivV * dw.z));
                 const v3 da = frame_to_world(q, d, q.omega); // the auxiliary direction (= hf_reparam_aux_kernel's)
-                const float b1 = a.pi_u[k * a.stride + i], b2 = a.pi_v[k * a.stride + i], b0 = 1.f - b1 - b2;
+                const float b1 = ka->a.pi_u[k * ka->a.stride + i], b2 = ka->a.pi_v[k * ka->a.stride + i], b0 = 1.f - b1 - b2;
                 v3 P[3];
                 float U[3], V[3];
                 int vi[3], vj[3];
-                prim_world(f, a.pi_prim[k * a.stride + i], P, U, V, vi, vj);
+                prim_world(load_field(&ka->f), ka->a.pi_prim[k * ka->a.stride + i], P, U, V, vi, vj);
                 const v3 p = mk3(__builtin_fmaf(P[0].x, b0, __builtin_fmaf(P[1].x, b1, P[2].x * b2)),
                                  __builtin_fmaf(P[0].y, b0, __builtin_fmaf(P[1].y, b1, P[2].y * b2)),
                                  __builtin_fmaf(P[0].z, b0, __builtin_fmaf(P[1].z, b1, P[2].z * b2)));
@@ -1641,11 +1683,12 @@ __global__ __launch_bounds__(HF_BLOCK, (HF_RB_TILE > 32 ? 2 : 5)) void hf_repara
                 const float gt = -dot3(gVd, po) * it * it;
                 axpy3(gt / (tt * dda), po, gp); // t's dependence on p (hf_adjoint_kernel, FollowShape branch)
                 // p = sum b_k P_k with detached barycentrics; dP_k/dh_k = s * (third column of to_world)
-                const v3 ez = mk3(f.to_world[2], f.to_world[6], f.to_world[10]);
+                const v3 ez = mk3(ka->f.to_world[2], ka->f.to_world[6], ka->f.to_world[10]);
                 const v3 z3 = mk3(0.f, 0.f, 0.f);
                 v3 gP0 = z3, gP1 = z3, gP2 = z3;
                 axpy3(b0, gp, gP0); axpy3(b1, gp, gP1); axpy3(b2, gp, gP2);
-                gh[0] = f.s * dot3(ez, gP0); gh[1] = f.s * dot3(ez, gP1); gh[2] = f.s * dot3(ez, gP2);
+                const float fs = ka->f.s;
+                gh[0] = fs * dot3(ez, gP0); gh[1] = fs * dot3(ez, gP1); gh[2] = fs * dot3(ez, gP2);
                 vr[0] = vi[0]; vr[1] = vi[1]; vr[2] = vi[2];
                 vc[0] = vj[0]; vc[1] = vj[1]; vc[2] = vj[2];
             }
@@ -1662,7 +1705,7 @@ __global__ __launch_bounds__(HF_BLOCK, (HF_RB_TILE > 32 ? 2 : 5)) void hf_repara
                         atomicAdd(acc + rr * HF_RB_TILE + cc, gh[c]);
                         rows |= 1ull << rr;
                     } else {
-                        atomicAdd(a.grad_h + (size_t) vr[c] * f.W + vc[c], gh[c]);
+                        atomicAdd(ka->a.grad_h + (size_t) vr[c] * ka->f.W + vc[c], gh[c]);
                     }
                 }
             }
@@ -1677,7 +1720,7 @@ __global__ __launch_bounds__(HF_BLOCK, (HF_RB_TILE > 32 ? 2 : 5)) void hf_repara
                 if (cc < HF_RB_TILE) {
                     const float v = acc[rr * HF_RB_TILE + cc];
                     if (v != 0.f) {
-                        atomicAdd(a.grad_h + (size_t) (ar + rr) * f.W + (ac + cc), v);
+                        atomicAdd(ka->a.grad_h + (size_t) (ar + rr) * ka->f.W + (ac + cc), v);
                         acc[rr * HF_RB_TILE + cc] = 0.f;
                     }
                 }
@@ -1696,7 +1739,9 @@ void hf_launch_reparam_backward(const hf_dev_field &f, const hf_reparam_args &ra
     a.g_div = ra.g_div; a.si_bt = ra.si_bt;
     a.pi_t = pi->t; a.pi_u = pi->prim_uv[0]; a.pi_v = pi->prim_uv[1]; a.pi_prim = pi->prim_index;
     a.grad_h = grad_h;
-    hipLaunchKernelGGL(hf_reparam_backward_kernel, dim3(grid_for(ra.n)), dim3(HF_BLOCK), 0, stream, f, a);
+    hf_reparam_bwd_kargs k;
+    k.f = f; k.a = a;
+    hipLaunchKernelGGL(hf_reparam_backward_kernel, dim3(grid_for(ra.n)), dim3(HF_BLOCK), 0, stream, k);
 }
 
 // ---------------------------------------------------------------------------------
