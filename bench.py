@@ -110,6 +110,10 @@ def main():
     def forward():
         _capi.check(lib.hf_ray_intersect(shape._h, R, C.byref(r_s), flags, None, C.byref(pi_s), C.byref(si_s), stream))
 
+    band = torch.tensor([N, 0], dtype=torch.int32, device=dev)  # rows that receive gradient (hf_adjoint_rows)
+    rows = [0, N]                                                # the rows the all-reduce covers: set after the warm-up
+    serial = [False]                                             # True: wait for the all-reduce inside the step
+
     def adjoint(events=None):
         b = step_no[0] % len(grads)
         step_no[0] += 1
@@ -119,12 +123,17 @@ def main():
         grad_h.zero_()
         if events:                        # the kernel alone: not the wait for an earlier all-reduce, not the memset
             events[0].record()
-        _capi.check(lib.hf_adjoint(shape._h, R, C.byref(r_s), C.byref(pi_s), flags, None, C.byref(g_s),
-                                   grad_h.data_ptr(), None, None, stream))
+        _capi.check(lib.hf_adjoint_rows(shape._h, R, C.byref(r_s), C.byref(pi_s), flags, None, C.byref(g_s),
+                                        grad_h.data_ptr(), None, None, band.data_ptr(), stream))
         if events:
             events[1].record()
-        if world > 1:                     # one collective per step, overlapping the next step's kernels
-            pending[b] = dist.all_reduce(grad_h, async_op=True)
+        if world > 1:
+            # one collective per step over the rows any rank touched (contiguous in memory); overlapped with the next
+            # step's kernels -- or waited for at once (`serial`: what a step needs whose optimiser consumes the
+            # gradient before the next forward)
+            pending[b] = dist.all_reduce(grad_h[rows[0]:rows[1]], async_op=True)
+            if serial[0]:
+                pending[b].wait(); pending[b] = None
         return grad_h
 
     def drain():
@@ -152,10 +161,18 @@ def main():
         else:
             forward(); adjoint()
 
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, 1)):
         step(False)
     drain()
     torch.cuda.synchronize()
+    # the rows ANY rank touched (static scene and camera: the band of the warm-up steps holds for the timed ones;
+    # a caller whose heights move re-measures it): union over ranks
+    lo_hi = band.to(torch.int64).clone()
+    if world > 1:
+        lo_t, hi_t = lo_hi[0:1].clone(), lo_hi[1:2].clone()
+        dist.all_reduce(lo_t, op=dist.ReduceOp.MIN); dist.all_reduce(hi_t, op=dist.ReduceOp.MAX)
+        lo_hi = torch.cat([lo_t, hi_t])
+    rows[0], rows[1] = int(lo_hi[0]), max(int(lo_hi[1]), int(lo_hi[0]))
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -175,6 +192,22 @@ def main():
 
     ms_step = 1e3 * elapsed / args.steps
     grad_h = grads[(step_no[0] - 1) % len(grads)]
+    grad_sample = grad_h.clone()          # the reduced gradient of the last timed step (checksums below)
+    # N > 1: the same steps with the all-reduce waited for inside the step (no overlap with the next forward) --
+    # reported beside the headline, which overlaps it
+    serial_ms = None
+    if world > 1:
+        serial[0] = True
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step(False)
+        drain()
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        st = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+        dist.all_reduce(st, op=dist.ReduceOp.MAX)
+        serial_ms = 1e3 * float(st.item()) / args.steps
+        serial[0] = False
     if world > 1:   # whole-job ray count: the one wavefront (strong) or one wavefront per rank (weak)
         rr = torch.tensor([float(R)], dtype=torch.float64, device=dev)
         dist.all_reduce(rr)
@@ -187,8 +220,9 @@ def main():
     adj_ms = sum(a.elapsed_time(b) for a, b in adj_ev) / len(adj_ev)
 
     # gradient sanity (size-independent property): grad is finite and non-zero
-    gnorm = float(torch.linalg.norm(grad_h.double()))
+    gnorm = float(torch.linalg.norm(grad_sample.double()))
     assert math.isfinite(gnorm) and gnorm > 0
+    gsum = float(grad_sample.double()[::7, ::5].sum())   # a second, position-dependent checksum of the reduced gradient
 
     out = None
     if rank == 0:
@@ -245,6 +279,11 @@ def main():
                           "parallelism": (f"one wavefront in 32x32-pixel tiles, tile b -> rank b % {world}; "
                                           if strong else f"one wavefront per rank ({world}); ") +
                                          "heights replicated, 1 async all-reduce of the gradient texture per step"},
+               "allreduce": {"rows": [rows[0], rows[1]], "bytes": (rows[1] - rows[0]) * N * 4,
+                             "overlap": "with the next step's kernels (headline)",
+                             "serial_ms_per_step": None if serial_ms is None else round(serial_ms, 4),
+                             "serial_value": None if serial_ms is None else round(total_rays / (serial_ms * 1e-3) / 1e6, 2)},
+               "grad_l2": gnorm, "grad_checksum": gsum,
                "roofline": roofline, "cpu_baseline": cpu, "other_launches_ms": extras}
         print(json.dumps(out), flush=True)
     if world > 1:

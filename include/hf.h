@@ -236,6 +236,16 @@ int hf_adjoint(const hf_field_t *hf, size_t n, const hf_rays_t *rays,
                const hf_pi_const_t *pi, uint32_t ray_flags, const uint8_t *active,
                const hf_si_grad_t *grad_si, float *grad_heights,
                float *const grad_o[3], float *const grad_d[3], hf_stream_t stream);
+/* hf_adjoint that also reports WHICH texture rows it added to: row_band (device, 2 x uint32, may be NULL) is updated
+ * with atomicMin / atomicMax to {lowest row touched, highest row touched + 1}; the caller initialises it to
+ * {height, 0} before the launches it wants covered.  Rows outside the band of every rank hold zeros in every rank's
+ * private gradient texture, so a multi-GPU host may all-reduce rows [lo, hi) only (hf_allreduce_grad on
+ * grad_heights + lo * width with count (hi - lo) * width).  (Reference: the gradient of the whole parameter buffer is
+ * what dr.backward leaves in params.grad, src/python/python/ad/integrators/common.py:312-329; no band there.) */
+int hf_adjoint_rows(const hf_field_t *hf, size_t n, const hf_rays_t *rays,
+                    const hf_pi_const_t *pi, uint32_t ray_flags, const uint8_t *active,
+                    const hf_si_grad_t *grad_si, float *grad_heights,
+                    float *const grad_o[3], float *const grad_d[3], uint32_t *row_band, hf_stream_t stream);
 
 /* ---- next row: minimal direct lighting on the wavefront ------- */
 

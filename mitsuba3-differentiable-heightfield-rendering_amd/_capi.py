@@ -66,6 +66,9 @@ SYMBOLS = {
     "hf_adjoint": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(hf_rays_t), C.POINTER(hf_pi_t),
                              C.c_uint32, _fp, C.POINTER(hf_si_grad_t), _fp,
                              C.POINTER(_fp * 3), C.POINTER(_fp * 3), C.c_void_p]),
+    "hf_adjoint_rows": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(hf_rays_t), C.POINTER(hf_pi_t),
+                             C.c_uint32, _fp, C.POINTER(hf_si_grad_t), _fp,
+                             C.POINTER(_fp * 3), C.POINTER(_fp * 3), C.c_void_p, C.c_void_p]),
     "hf_direct_lighting": (C.c_int, [C.c_size_t, C.c_uint32, C.POINTER(_fp * 3), C.POINTER(_fp * 3), _fp, C.c_uint32,
                                      C.POINTER(hf_dir_light_t), C.c_float, C.POINTER(_fp), _fp, C.c_void_p]),
     "hf_direct_lighting_adjoint": (C.c_int, [C.c_size_t, C.c_uint32, C.POINTER(_fp * 3), C.POINTER(_fp * 3), _fp,

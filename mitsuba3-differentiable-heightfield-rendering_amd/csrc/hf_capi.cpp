@@ -466,10 +466,10 @@ extern "C" int hf_ray_intersect(const hf_field_t *hf, size_t n, const hf_rays_t 
     return HF_OK;
 }
 
-extern "C" int hf_adjoint(const hf_field_t *hf, size_t n, const hf_rays_t *rays, const hf_pi_const_t *pi,
-                          uint32_t ray_flags, const uint8_t *active, const hf_si_grad_t *grad_si,
-                          float *grad_heights, float *const grad_o[3], float *const grad_d[3],
-                          hf_stream_t stream) {
+extern "C" int hf_adjoint_rows(const hf_field_t *hf, size_t n, const hf_rays_t *rays, const hf_pi_const_t *pi,
+                               uint32_t ray_flags, const uint8_t *active, const hf_si_grad_t *grad_si,
+                               float *grad_heights, float *const grad_o[3], float *const grad_d[3],
+                               uint32_t *row_band, hf_stream_t stream) {
     int rc = check_rays("hf_adjoint", hf, n, rays);
     if (rc) return rc;
     if ((rc = check_flags("hf_adjoint", ray_flags))) return rc;
@@ -477,10 +477,17 @@ extern "C" int hf_adjoint(const hf_field_t *hf, size_t n, const hf_rays_t *rays,
     if (!grad_si) return fail(HF_EINVAL, "hf_adjoint: NULL grad_si");
     if (grad_o && (!grad_o[0] || !grad_o[1] || !grad_o[2])) return fail(HF_EINVAL, "hf_adjoint: NULL grad_o array");
     if (grad_d && (!grad_d[0] || !grad_d[1] || !grad_d[2])) return fail(HF_EINVAL, "hf_adjoint: NULL grad_d array");
-    hf_launch_adjoint(hf->dev, n, rays, pi, active, grad_si, ray_flags, grad_heights, grad_o, grad_d,
+    hf_launch_adjoint(hf->dev, n, rays, pi, active, grad_si, ray_flags, grad_heights, grad_o, grad_d, row_band,
                       (hipStream_t) stream);
     HF_HIP(hipGetLastError());
     return HF_OK;
+}
+
+extern "C" int hf_adjoint(const hf_field_t *hf, size_t n, const hf_rays_t *rays, const hf_pi_const_t *pi,
+                          uint32_t ray_flags, const uint8_t *active, const hf_si_grad_t *grad_si,
+                          float *grad_heights, float *const grad_o[3], float *const grad_d[3],
+                          hf_stream_t stream) {
+    return hf_adjoint_rows(hf, n, rays, pi, ray_flags, active, grad_si, grad_heights, grad_o, grad_d, nullptr, stream);
 }
 
 // ---- minimal direct lighting --------------------------------------------------

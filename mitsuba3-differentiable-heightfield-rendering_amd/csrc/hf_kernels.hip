@@ -1351,6 +1351,7 @@ struct hf_adjoint_args {
     uint32_t flags;
     float *grad_h;
     float *go[3], *gd[3];
+    uint32_t *row_band; // optional: {lowest texture row that received a contribution, highest + 1}, atomicMin / atomicMax
 };
 typedef const __attribute__((address_space(4))) hf_adjoint_args *hf_adj_kargs;
 __device__ __forceinline__ hf_adj_kargs adj_kargs() {
@@ -1374,6 +1375,7 @@ __global__ __launch_bounds__(HF_BLOCK, 5) void hf_adjoint_kernel(hf_adjoint_args
     float *acc = s_acc[threadIdx.x >> 6];
     const uint32_t lane = threadIdx.x & 63u;
     for (uint32_t k = lane; k < HF_ADJ_TILE * HF_ADJ_TILE; k += 64) acc[k] = 0.f;
+    uint32_t row_lo = 0xFFFFFFFFu, row_hi = 0u; // rows this lane scattered to (hf_adjoint_rows)
     const size_t stride = (size_t) gridDim.x * HF_BLOCK;
     for (size_t ub = (size_t) blockIdx.x * HF_BLOCK + (threadIdx.x & ~63u);; ub += stride) { // whole waves stay in the loop (ballots below)
         hf_adj_kargs ka = adj_kargs();
@@ -1498,6 +1500,8 @@ __global__ __launch_bounds__(HF_BLOCK, 5) void hf_adjoint_kernel(hf_adjoint_args
                 vr[0] = vi[0]; vr[1] = vi[1]; vr[2] = vi[2];
                 vc[0] = vj[0]; vc[1] = vj[1]; vc[2] = vj[2];
                 scatter = true;
+                row_lo = min(row_lo, (uint32_t) min(vi[0], min(vi[1], vi[2])));
+                row_hi = max(row_hi, (uint32_t) max(vi[0], max(vi[1], vi[2])) + 1u);
             }
         }
         const uint64_t sm = __ballot(scatter);
@@ -1541,11 +1545,22 @@ __global__ __launch_bounds__(HF_BLOCK, 5) void hf_adjoint_kernel(hf_adjoint_args
             if (kb->gd[0]) { (kb->gd[0] + ub)[lo] = gd.x; (kb->gd[1] + ub)[lo] = gd.y; (kb->gd[2] + ub)[lo] = gd.z; }
         }
     }
+    uint32_t *band = adj_kargs()->row_band;
+    if (band) {
+        // Per wave that scattered at all -- and only when it WIDENS the band: 65 k waves doing two atomics each on the
+        // same two words cost the launch 0.9 ms (same-address atomics serialise); a relaxed read first (a stale value
+        // only costs a redundant atomic) leaves the handful of waves that see the band grow.
+        const uint32_t wl = wave_min_u32(row_lo), wh = wave_max_u32(row_hi);
+        if (lane == 0u && wl < wh) {
+            if (wl < __hip_atomic_load(band, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(band, wl);
+            if (wh > __hip_atomic_load(band + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(band + 1, wh);
+        }
+    }
 }
 
 void hf_launch_adjoint(const hf_dev_field &f, size_t n, const hf_rays_t *rays, const hf_pi_const_t *pi,
                        const uint8_t *active, const hf_si_grad_t *gs, uint32_t flags, float *grad_h,
-                       float *const grad_o[3], float *const grad_d[3], hipStream_t stream) {
+                       float *const grad_o[3], float *const grad_d[3], uint32_t *row_band, hipStream_t stream) {
     if (n == 0) return;
     const hf_pi_cdev p = { pi->t, pi->prim_uv[0], pi->prim_uv[1], pi->prim_index };
     hf_grad_dev g;
@@ -1557,6 +1572,7 @@ void hf_launch_adjoint(const hf_dev_field &f, size_t n, const hf_rays_t *rays, c
     g.uv[0] = gs->uv[0]; g.uv[1] = gs->uv[1];
     hf_adjoint_args a;
     a.f = f; a.n = n; a.rays = to_dev(rays); a.pi = p; a.active = active; a.g = g; a.flags = flags; a.grad_h = grad_h;
+    a.row_band = row_band;
     for (int k = 0; k < 3; ++k) { a.go[k] = grad_o ? grad_o[k] : nullptr; a.gd[k] = grad_d ? grad_d[k] : nullptr; }
     if (grad_o || grad_d) hipLaunchKernelGGL(hf_adjoint_kernel<true>, dim3(grid_for(n)), dim3(HF_BLOCK), 0, stream, a);
     else                  hipLaunchKernelGGL(hf_adjoint_kernel<false>, dim3(grid_for(n)), dim3(HF_BLOCK), 0, stream, a);

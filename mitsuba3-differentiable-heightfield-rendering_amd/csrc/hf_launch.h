@@ -19,7 +19,7 @@ void hf_launch_si(const hf_dev_field &f, size_t n, const hf_rays_t *rays, const 
                   const uint8_t *active, const hf_si_t *si, uint32_t flags, hipStream_t stream);
 void hf_launch_adjoint(const hf_dev_field &f, size_t n, const hf_rays_t *rays, const hf_pi_const_t *pi,
                        const uint8_t *active, const hf_si_grad_t *gs, uint32_t flags, float *grad_h,
-                       float *const grad_o[3], float *const grad_d[3], hipStream_t stream);
+                       float *const grad_o[3], float *const grad_d[3], uint32_t *row_band, hipStream_t stream);
 // c1 = (float)(1 - beta1), c2 = (float)(1 - beta2): the differences are Python doubles in optimizers.py:279-280,
 // rounded once when they meet the float32 gradient
 void hf_launch_adam(size_t n, float *h, const float *g, float *m, float *v, float lr_t, float beta1, float beta2,

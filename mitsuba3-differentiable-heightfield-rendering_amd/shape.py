@@ -514,7 +514,7 @@ class Heightfield:
         return si
 
     # ---- adjoint ------------------------------------------------------------------------------
-    def _adjoint_raw(self, o, d, maxt, t, uv, prim, ray_flags, active_u8, g, grad_h, grad_od):
+    def _adjoint_raw(self, o, d, maxt, t, uv, prim, ray_flags, active_u8, g, grad_h, grad_od, row_band=None):
         n = o.shape[1]
         rays = self._rays_struct(o, d, maxt)
         pis = self._pi_struct(t, uv, prim)
@@ -524,16 +524,23 @@ class Heightfield:
             rows = _rows(grad_od, n)
             go = (C.c_void_p * 3)(*rows[0:3])
             gd = (C.c_void_p * 3)(*rows[3:6])
-        check(_capi.lib().hf_adjoint(self._h, n, C.byref(rays), C.byref(pis), int(ray_flags),
-                                     active_u8.data_ptr() if active_u8 is not None else None, C.byref(gs),
-                                     grad_h.data_ptr() if grad_h is not None else None,
-                                     C.byref(go) if go is not None else None,
-                                     C.byref(gd) if gd is not None else None, self._stream()))
+        check(_capi.lib().hf_adjoint_rows(self._h, n, C.byref(rays), C.byref(pis), int(ray_flags),
+                                          active_u8.data_ptr() if active_u8 is not None else None, C.byref(gs),
+                                          grad_h.data_ptr() if grad_h is not None else None,
+                                          C.byref(go) if go is not None else None,
+                                          C.byref(gd) if gd is not None else None,
+                                          row_band.data_ptr() if row_band is not None else None, self._stream()))
+
+    def new_row_band(self):
+        """{height, 0} as int32[2] on the device: the initial value of hf_adjoint_rows' row band."""
+        return torch.tensor([self.height, 0], dtype=torch.int32, device=self.device)
 
     def adjoint(self, ray, pi, grad_si, ray_flags=RayFlags.All, active=True, grad_heightfield=None,
-                ray_grads=False):
+                ray_grads=False, row_band=None):
         """Explicit adjoint: accumulate dL/dheight for upstream gradients `grad_si`
-        ([18, n]: t, p, n, uv, sh_frame.n, dp_du, dp_dv) into `grad_heightfield` ([H, W])."""
+        ([18, n]: t, p, n, uv, sh_frame.n, dp_du, dp_dv) into `grad_heightfield` ([H, W]).
+        row_band (int32[2] device tensor from new_row_band(), optional): updated to {lowest texture row that
+        received a contribution, highest + 1} (hf_adjoint_rows): what a multi-GPU host needs to all-reduce."""
         self._check_ray(ray)
         n = len(ray)
         g = _as_f32(grad_si, self.device)
@@ -543,7 +550,7 @@ class Heightfield:
         keep, _ = self._mask(active, n)
         grad_od = torch.empty((6, n), dtype=torch.float32, device=self.device) if ray_grads else None
         self._adjoint_raw(ray.o, ray.d, ray.maxt, pi.t, pi.prim_uv, pi.prim_index, ray_flags, keep, g,
-                          grad_heightfield, grad_od)
+                          grad_heightfield, grad_od, row_band)
         if ray_grads:
             return grad_heightfield, grad_od[0:3], grad_od[3:6]
         return grad_heightfield

@@ -73,3 +73,35 @@ def test_virtual_ranks_reproduce_single_gpu(hf, world):
         gh_sum += gh
     err = float(torch.linalg.norm((gh_sum - gh_f).double()) / torch.linalg.norm(gh_f.double()))
     assert err < 1e-5, err     # float atomics: order of the additions differs, nothing else
+
+
+@pytest.mark.gpu
+def test_adjoint_row_band_is_the_rows_that_received_gradient(hf):
+    """hf_adjoint_rows: the reported band [lo, hi) is exactly the span of the texture rows of the hit triangles'
+    vertices (cell row cy -> vertex rows cy, cy + 1), accumulated over several launches -- what a multi-GPU host may
+    restrict its all-reduce to (BASELINE configs[3]: one all-reduce of the gradient texture per step)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    N, film, spp = 512, 128, 4
+    h = hf.workload.sine_heights(N, N, device=dev)
+    shape = hf.Heightfield(heightfield=h, max_height=0.5)
+    rays = hf.workload.ortho_rays(film, film, spp, dev)
+    ray = hf.Ray3f(rays[0:3], rays[3:6], rays[6])
+    pi = shape.ray_intersect_preliminary(ray)
+    cy = (pi.prim_index.to(torch.int64) >> 1) // (N - 1)
+    keep = pi.is_valid() & (cy >= 100) & (cy < 237)               # only the hits of a band of cell rows take part
+    assert int(keep.sum()) > 1000
+    g = torch.zeros((18, len(ray)), device=dev); g[0] = 1.0
+    band = shape.new_row_band()
+    grad = torch.zeros((N, N), device=dev)
+    half = len(ray) // 2
+    for sl in (slice(0, half), slice(half, len(ray))):            # two launches, one band
+        r2 = hf.Ray3f(rays[0:3, sl].contiguous(), rays[3:6, sl].contiguous(), rays[6, sl].contiguous())
+        p2 = shape.ray_intersect_preliminary(r2)
+        shape.adjoint(r2, p2, g[:, sl].contiguous(), active=keep[sl].contiguous(), grad_heightfield=grad, row_band=band)
+    lo, hi = (int(x) for x in band.cpu())
+    assert lo == int(cy[keep].min()) and hi == int(cy[keep].max()) + 2
+    assert float(grad[:lo].abs().max()) == 0.0 and float(grad[hi:].abs().max()) == 0.0 and float(grad[lo:hi].abs().max()) > 0
+    untouched = shape.new_row_band()                              # a launch without hits leaves the band empty
+    shape.adjoint(ray, pi, g, active=torch.zeros_like(keep), row_band=untouched)
+    assert [int(x) for x in untouched.cpu()] == [N, 0]
