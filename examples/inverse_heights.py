@@ -11,12 +11,16 @@ A minimal direct-lighting differentiable render on top of the heightfield shape:
         optimiser step, util.py:185-232, scene.cpp:343-385)
 Geometry is attached (prb-style).  --silhouette adds the discontinuity term the way prb_reparam.py:317-366 does for
 the camera ray: the primary rays go through hf_amd.reparameterize_ray (identity in primal mode), the intersection is
-differentiated w.r.t. the reparameterised direction as well, and every sample is weighted by the determinant; the
-shading of that variant is written in torch (per-sample weights are not part of hf_direct_lighting).
+differentiated w.r.t. the reparameterised direction as well, and every sample is weighted by the determinant
+(hf_direct_lighting's per-sample weight row: direct_reparam.py:164-180).
 
     python examples/inverse_heights.py [--grid 128 --film 256 --steps 100]
-With torch.distributed initialised (torchrun), every rank renders its own spp seed and the gradient
-texture is summed with one all-reduce per step.
+Sharded (BASELINE configs[3] / [4]): under torchrun (torch.distributed initialised by this script) rank r renders the
+image tiles hf_amd.workload.partition_tiles(film, film, world)[r] of the ONE wavefront -- targets sliced the same
+way, the image loss normalised by the pixel count of the whole film so that the ranks' losses add up to the
+single-rank loss -- and the gradient texture is summed with one all-reduce per step; the Adam step is replicated.
+--virtual-ranks V runs the same partition on one device, shard after shard (what tests/test_gpu_inverse_loop.py
+compares with the unsharded loop).
 """
 import argparse
 import math
@@ -33,17 +37,14 @@ LIGHTS = torch.tensor([[0.5, 0.2, 0.84], [-0.5, 0.3, 0.81], [0.1, -0.6, 0.79], [
 
 
 def render_reparameterized(shape, ray, lights, spp, aux=8, kappa=2e4, seed=0):
-    """primary rays through reparameterize_ray; per-sample diffuse shading x determinant, box film -- all in torch on
-    top of the differentiable si rows (the gradient reaches the heights through hf_adjoint and the auxiliary rays)"""
+    """primary rays through reparameterize_ray; per-sample diffuse shading x determinant and the box film in
+    hf_direct_lighting (weight row = the determinant); the gradient reaches the heights through hf_adjoint (shading
+    normal), the auxiliary rays (reparameterised direction) and the determinant (weight gradient)"""
     d, det = hf_amd.reparameterize_ray(shape, ray, num_rays=aux, kappa=kappa, exponent=3.0, seed=seed)
     ray2 = hf_amd.Ray3f(ray.o, d, ray.maxt)
     si = shape.ray_intersect(ray2, hf_amd.RayFlags.All)
     valid = si.is_valid()
-    lights = lights.to(si.sh_frame.n.device)
-    facing = valid & (-(si.sh_frame.n * d).sum(0) > 0)
-    cos = torch.clamp((lights[:, :3, None] * si.sh_frame.n[None]).sum(1), min=0.0)            # [K, rays]
-    sample = torch.where(facing[None], cos * (lights[:, 3:4] / math.pi), torch.zeros_like(cos)) * det[None]
-    images = sample.reshape(len(lights), -1, spp).mean(2)
+    images = hf_amd.direct_lighting(si, ray2, lights, albedo=1.0, spp=spp, weight=det)
     depth = torch.where(valid, si.t, torch.zeros_like(si.t))
     return images, depth, valid
 
@@ -77,34 +78,60 @@ def centred_error(h, target):
 
 
 def run(grid=128, film=256, spp=1, steps=100, lr=0.02, device="cuda", verbose=True, seed=0, shadows=False,
-        depth_weight=0.0, silhouette=False, aux=8, kappa=2e4, gaussian_film=False):
+        depth_weight=0.0, silhouette=False, aux=8, kappa=2e4, gaussian_film=False, virtual_ranks=0, record=None):
+    """record (optional list): receives the height texture after every step (trajectory comparisons in the tests)"""
+    import torch.distributed as dist
     dev = torch.device(device)
     lights = torch.cat([LIGHTS / LIGHTS.norm(dim=1, keepdim=True), torch.full((len(LIGHTS), 1), math.pi)], 1)  # E = pi
     target_h = hf_amd.workload.sine_heights(grid, grid, device=dev)
-    # camera looking down at 30 degrees off vertical so that every ray meets the surface
-    rays = hf_amd.workload.ortho_rays(film, film, spp, dev, seed=seed, origin=(0.6, 0.35, 2.0),
-                                      target=(0.0, 0.0, 0.25), scale=(0.95, 0.95, 1.0))
-    ray = hf_amd.Ray3f(rays[0:3], rays[3:6], rays[6])
-    flm = (hf_amd.workload.film_positions(film, film, spp, dev, seed=seed), film, film) if gaussian_film else None
+    # ---- the shards this process renders: its rank's image tiles under torch.distributed, all V shards one after
+    # the other with --virtual-ranks V, else the whole film ----
+    distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    if distributed:
+        assert not gaussian_film, "the Gaussian film splats across tile borders: not sharded"
+        shard_pixels = [hf_amd.workload.partition_tiles(film, film, dist.get_world_size())[dist.get_rank()]]
+    elif virtual_ranks and virtual_ranks > 1:
+        assert not gaussian_film
+        shard_pixels = hf_amd.workload.partition_tiles(film, film, virtual_ranks)
+    else:
+        shard_pixels = [None]
+    npix_total = film * film
     target = hf_amd.Heightfield(heightfield=target_h, max_height=0.5)
-    with torch.no_grad():
-        tgt_img, tgt_depth, tgt_valid = render(target, ray, lights, spp, shadows, film=flm)
+    shards = []
+    for pixels in shard_pixels:
+        # camera looking down at 30 degrees off vertical so that every ray meets the surface
+        rays = hf_amd.workload.ortho_rays(film, film, spp, dev, seed=seed, origin=(0.6, 0.35, 2.0),
+                                          target=(0.0, 0.0, 0.25), scale=(0.95, 0.95, 1.0), pixels=pixels)
+        ray = hf_amd.Ray3f(rays[0:3], rays[3:6], rays[6])
+        flm = (hf_amd.workload.film_positions(film, film, spp, dev, seed=seed), film, film) if gaussian_film else None
+        with torch.no_grad():
+            tgt_img, tgt_depth, tgt_valid = render(target, ray, lights, spp, shadows, film=flm)
+        shards.append((ray, flm, tgt_img, tgt_depth, tgt_valid))
     shape = hf_amd.Heightfield(heightfield=torch.full_like(target_h, 0.5), max_height=0.5)
     shape.heightfield.requires_grad_(True)
     opt = hf_amd.Adam(shape, lr=lr)                       # hf_adam_step: optimizers.py:263-300 + params.update
     hist = []
     t0 = time.perf_counter()
+    n_rays = sum(len(sh[0]) for sh in shards)
     for it in range(steps):
         opt.zero_grad()
-        images, depth, valid = render(shape, ray, lights, spp, shadows, silhouette, aux, kappa, film=flm)
-        both = valid & tgt_valid
-        loss = ((images - tgt_img) ** 2).sum(0).mean()          # the multi-light renders only (configs[4])
-        if depth_weight > 0:                                    # optional extra supervision, off by default
-            loss = loss + depth_weight * (((depth - tgt_depth) ** 2) * both).sum() / both.sum()
-        loss.backward()
+        total = 0.0
+        for ray, flm, tgt_img, tgt_depth, tgt_valid in shards:    # (backward accumulates into heightfield.grad)
+            images, depth, valid = render(shape, ray, lights, spp, shadows, silhouette, aux, kappa, film=flm)
+            both = valid & tgt_valid
+            # the multi-light renders only (configs[4]); mean over the pixels of the WHOLE film: shard losses add up
+            loss = ((images - tgt_img) ** 2).sum() / npix_total
+            if depth_weight > 0:                                    # optional extra supervision, off by default
+                loss = loss + depth_weight * (((depth - tgt_depth) ** 2) * both).sum() / (npix_total * spp)
+            loss.backward()
+            total = total + loss.detach()
+        if distributed:                                             # image loss and gradient texture: sums over ranks
+            dist.all_reduce(total)
         hf_amd.allreduce_gradient(shape.heightfield.grad)
-        opt.step()                                            # Adam update + rebuild of the acceleration data
-        hist.append(float(loss.detach()))
+        opt.step()                                            # Adam update + rebuild of the acceleration data (replicated)
+        hist.append(float(total))
+        if record is not None:
+            record.append(shape.heightfield.detach().clone())
         if it == 0:  # the first step pays the one-off costs (code-object load, allocator warm-up)
             torch.cuda.synchronize()
             t_first = time.perf_counter() - t0
@@ -116,7 +143,7 @@ def run(grid=128, film=256, spp=1, steps=100, lr=0.02, device="cuda", verbose=Tr
     wall = time.perf_counter() - t0
     err = float((shape.heightfield.detach() - target_h).abs().mean())
     if verbose:
-        print(f"{steps} Adam steps, {len(ray)} rays/step: {wall:.2f} s wall-clock end to end "
+        print(f"{steps} Adam steps, {n_rays} rays/step on this process: {wall:.2f} s wall-clock end to end "
               f"(first step {1e3 * t_first:.0f} ms, then {1e3 * (wall - t_first) / max(1, steps - 1):.2f} ms/step)")
     run.last_centred_error = centred_error(shape.heightfield.detach(), target_h)
     run.start_centred_error = centred_error(torch.full_like(target_h, 0.5), target_h)
@@ -135,6 +162,18 @@ if __name__ == "__main__":
     ap.add_argument("--silhouette", action="store_true", help="reparameterised primary rays (discontinuity term)")
     ap.add_argument("--aux", type=int, default=8, help="auxiliary rays per primary ray of --silhouette")
     ap.add_argument("--gaussian-film", action="store_true", help="Gaussian reconstruction filter instead of the box film")
+    ap.add_argument("--virtual-ranks", type=int, default=0, help="render the tile partition of V ranks on this one device")
     a = ap.parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:   # torchrun: one process per GPU, RCCL (HF_BENCH_BACKEND=gloo: ranks may share a device)
+        import torch.distributed as dist
+        backend = os.environ.get("HF_BENCH_BACKEND", "nccl")
+        local = int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count()
+        torch.cuda.set_device(local)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend, rank=int(os.environ["RANK"]), world_size=world)
     run(a.grid, a.film, a.spp, a.steps, a.lr, shadows=a.shadows, depth_weight=a.depth_weight, silhouette=a.silhouette,
-        aux=a.aux, gaussian_film=a.gaussian_film)
+        aux=a.aux, gaussian_film=a.gaussian_film, virtual_ranks=a.virtual_ranks,
+        verbose=int(os.environ.get("RANK", "0")) == 0)
+    if world > 1:
+        dist.destroy_process_group()

@@ -278,6 +278,18 @@ int hf_direct_lighting_adjoint(size_t n, uint32_t spp, const float *const sh_n[3
                                const float *t, uint32_t n_lights, const hf_dir_light_t *lights, float albedo,
                                const uint8_t *const *vis, const float *grad_image, float *const grad_sh_n[3],
                                hf_stream_t stream);
+/* The same pair with a per-sample WEIGHT (n floats, device): every light's contribution of sample i is multiplied by
+ * weight[i] before the film -- the determinant of a reparameterised camera ray, which direct_reparam.py:164-180 /
+ * prb_reparam.py:317-366 multiply the sample by.  The adjoint also returns dL/dweight (grad_weight, n floats,
+ * overwritten; may be NULL), the gradient that goes on to hf_reparam_*'s divergence input.  weight == NULL: as above. */
+int hf_direct_lighting_weighted(size_t n, uint32_t spp, const float *const sh_n[3], const float *const d[3],
+                                const float *t, const float *weight, uint32_t n_lights, const hf_dir_light_t *lights,
+                                float albedo, const uint8_t *const *vis, float *image, hf_stream_t stream);
+int hf_direct_lighting_weighted_adjoint(size_t n, uint32_t spp, const float *const sh_n[3], const float *const d[3],
+                                        const float *t, const float *weight, uint32_t n_lights,
+                                        const hf_dir_light_t *lights, float albedo, const uint8_t *const *vis,
+                                        const float *grad_image, float *const grad_sh_n[3], float *grad_weight,
+                                        hf_stream_t stream);
 
 /* The same under POINT lights (src/emitters/point.cpp:106-123: direction d = position - si.p, radiance
  * intensity / |d|^2): sample value albedo/pi * intensity / r^2 * max(0, <sh_n, l>) with l = (position - p) / r, same

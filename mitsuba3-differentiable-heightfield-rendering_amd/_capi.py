@@ -74,6 +74,12 @@ SYMBOLS = {
     "hf_direct_lighting_adjoint": (C.c_int, [C.c_size_t, C.c_uint32, C.POINTER(_fp * 3), C.POINTER(_fp * 3), _fp,
                                              C.c_uint32, C.POINTER(hf_dir_light_t), C.c_float, C.POINTER(_fp), _fp,
                                              C.POINTER(_fp * 3), C.c_void_p]),
+    "hf_direct_lighting_weighted": (C.c_int, [C.c_size_t, C.c_uint32, C.POINTER(_fp * 3), C.POINTER(_fp * 3), _fp, _fp,
+                                              C.c_uint32, C.POINTER(hf_dir_light_t), C.c_float, C.POINTER(_fp), _fp,
+                                              C.c_void_p]),
+    "hf_direct_lighting_weighted_adjoint": (C.c_int, [C.c_size_t, C.c_uint32, C.POINTER(_fp * 3), C.POINTER(_fp * 3), _fp,
+                                                      _fp, C.c_uint32, C.POINTER(hf_dir_light_t), C.c_float,
+                                                      C.POINTER(_fp), _fp, C.POINTER(_fp * 3), _fp, C.c_void_p]),
     "hf_point_lighting": (C.c_int, [C.c_size_t, C.c_uint32, C.POINTER(_fp * 3), C.POINTER(_fp * 3), _fp, C.POINTER(_fp * 3),
                                     C.c_uint32, C.POINTER(hf_dir_light_t), C.c_float, C.POINTER(_fp), _fp, C.c_void_p]),
     "hf_point_lighting_adjoint": (C.c_int, [C.c_size_t, C.c_uint32, C.POINTER(_fp * 3), C.POINTER(_fp * 3), _fp,

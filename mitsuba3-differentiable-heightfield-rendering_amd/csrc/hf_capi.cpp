@@ -502,6 +502,7 @@ static int pack_lights(const char *who, size_t n, uint32_t spp, const float *con
         return fail(HF_EINVAL, "%s: 1..%d lights supported (got %u)", who, HF_MAX_LIGHTS, n_lights);
     if ((size_t) (n / spp) * n_lights >= ((size_t) 1 << 32)) return fail(HF_EINVAL, "%s: image too large", who);
     L.n = n_lights;
+    L.weight = nullptr; L.grad_weight = nullptr;
     for (uint32_t k = 0; k < HF_MAX_LIGHTS; ++k) {
         const bool on = k < n_lights;
         for (int c = 0; c < 3; ++c) L.l[k][c] = on ? lights[k].to_light[c] : 0.f;
@@ -511,30 +512,45 @@ static int pack_lights(const char *who, size_t n, uint32_t spp, const float *con
     return HF_OK;
 }
 
-extern "C" int hf_direct_lighting(size_t n, uint32_t spp, const float *const sh_n[3], const float *const d[3],
-                                  const float *t, uint32_t n_lights, const hf_dir_light_t *lights, float albedo,
-                                  const uint8_t *const *vis, float *image, hf_stream_t stream) {
+extern "C" int hf_direct_lighting_weighted(size_t n, uint32_t spp, const float *const sh_n[3], const float *const d[3],
+                                           const float *t, const float *weight, uint32_t n_lights,
+                                           const hf_dir_light_t *lights, float albedo, const uint8_t *const *vis,
+                                           float *image, hf_stream_t stream) {
     hf_lights_dev L;
     const int rc = pack_lights("hf_direct_lighting", n, spp, sh_n, d, t, n_lights, lights, albedo, vis, L);
     if (rc != HF_OK) return rc;
     if (!image) return fail(HF_EINVAL, "hf_direct_lighting: NULL image");
+    L.weight = weight;
     hf_launch_direct(n, spp, sh_n, d, t, nullptr, L, image, (hipStream_t) stream);
     HF_HIP(hipGetLastError());
     return HF_OK;
 }
-
-extern "C" int hf_direct_lighting_adjoint(size_t n, uint32_t spp, const float *const sh_n[3], const float *const d[3],
-                                          const float *t, uint32_t n_lights, const hf_dir_light_t *lights,
-                                          float albedo, const uint8_t *const *vis, const float *grad_image,
-                                          float *const grad_sh_n[3], hf_stream_t stream) {
+extern "C" int hf_direct_lighting(size_t n, uint32_t spp, const float *const sh_n[3], const float *const d[3],
+                                  const float *t, uint32_t n_lights, const hf_dir_light_t *lights, float albedo,
+                                  const uint8_t *const *vis, float *image, hf_stream_t stream) {
+    return hf_direct_lighting_weighted(n, spp, sh_n, d, t, nullptr, n_lights, lights, albedo, vis, image, stream);
+}
+extern "C" int hf_direct_lighting_weighted_adjoint(size_t n, uint32_t spp, const float *const sh_n[3],
+                                                   const float *const d[3], const float *t, const float *weight,
+                                                   uint32_t n_lights, const hf_dir_light_t *lights, float albedo,
+                                                   const uint8_t *const *vis, const float *grad_image,
+                                                   float *const grad_sh_n[3], float *grad_weight, hf_stream_t stream) {
     hf_lights_dev L;
     const int rc = pack_lights("hf_direct_lighting_adjoint", n, spp, sh_n, d, t, n_lights, lights, albedo, vis, L);
     if (rc != HF_OK) return rc;
     if (!grad_image || !grad_sh_n || !grad_sh_n[0] || !grad_sh_n[1] || !grad_sh_n[2])
         return fail(HF_EINVAL, "hf_direct_lighting_adjoint: NULL gradient array");
+    L.weight = weight; L.grad_weight = grad_weight;
     hf_launch_direct_adjoint(n, spp, sh_n, d, t, nullptr, L, grad_image, grad_sh_n, nullptr, (hipStream_t) stream);
     HF_HIP(hipGetLastError());
     return HF_OK;
+}
+extern "C" int hf_direct_lighting_adjoint(size_t n, uint32_t spp, const float *const sh_n[3], const float *const d[3],
+                                          const float *t, uint32_t n_lights, const hf_dir_light_t *lights,
+                                          float albedo, const uint8_t *const *vis, const float *grad_image,
+                                          float *const grad_sh_n[3], hf_stream_t stream) {
+    return hf_direct_lighting_weighted_adjoint(n, spp, sh_n, d, t, nullptr, n_lights, lights, albedo, vis, grad_image,
+                                               grad_sh_n, nullptr, stream);
 }
 
 static bool all3(const float *const p[3]) { return p && p[0] && p[1] && p[2]; }

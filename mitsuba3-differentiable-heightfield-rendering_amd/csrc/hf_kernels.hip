@@ -1822,6 +1822,7 @@ __global__ __launch_bounds__(HF_BLOCK) void hf_direct_kernel(size_t n, uint32_t 
         }
         const float co = dot3(nn, l);
         float c = (lit && co > 0.f && (L.vis[k] ? L.vis[k][ii] != 0 : true)) ? wk * co : 0.f;
+        if (L.weight) c *= L.weight[ii];
         if (pow2) {
             // butterfly over the g = min(spp, 64) lanes of a pixel: DPP within rows of 16, cross-lane beyond
             if (g > 1u) c += HF_DPP_ADD(c, 0xB1);   // quad_perm [1,0,3,2]
@@ -1855,6 +1856,8 @@ __global__ __launch_bounds__(HF_BLOCK) void hf_direct_adjoint_kernel(size_t n, u
     v3 g = mk3(0.f, 0.f, 0.f), gq = mk3(0.f, 0.f, 0.f);
     v3 p = mk3(0.f, 0.f, 0.f);
     if (POINT) p = mk3(pp.p[0][i], pp.p[1][i], pp.p[2][i]);
+    const float wgt = L.weight ? L.weight[i] : 1.f;
+    float gw = 0.f; // dL/dweight: the unweighted sample values against the image gradient
     for (uint32_t k = 0; k < L.n; ++k) {
         v3 l = mk3(L.l[k][0], L.l[k][1], L.l[k][2]);
         float ir = 1.f;
@@ -1866,6 +1869,8 @@ __global__ __launch_bounds__(HF_BLOCK) void hf_direct_adjoint_kernel(size_t n, u
         const float co = dot3(nn, l);
         if (lit && co > 0.f && (L.vis[k] ? L.vis[k][i] != 0 : true)) {
             float w = (L.w[k] * inv_spp) * gimg[k * npix + pix];
+            if (!POINT) gw = __builtin_fmaf(w, co, gw);
+            w *= wgt;
             if (POINT) {
                 w = w * (ir * ir);
                 const float wp = w * ir, c3 = 3.f * co;
@@ -1878,6 +1883,7 @@ __global__ __launch_bounds__(HF_BLOCK) void hf_direct_adjoint_kernel(size_t n, u
     }
     gn.p[0][i] = g.x; gn.p[1][i] = g.y; gn.p[2][i] = g.z;
     if (POINT) { gp.p[0][i] = gq.x; gp.p[1][i] = gq.y; gp.p[2][i] = gq.z; }
+    if (!POINT && L.grad_weight) L.grad_weight[i] = gw;
 }
 
 // ---------------------------------------------------------------------------------

@@ -29,6 +29,8 @@ struct hf_lights_dev {
     float w[HF_MAX_LIGHTS]; // albedo/pi * irradiance
     const uint8_t *vis[HF_MAX_LIGHTS];
     uint32_t n;
+    const float *weight;  // optional per-sample factor of every light's contribution (hf_direct_lighting_weighted)
+    float *grad_weight;   // adjoint, optional: dL/dweight per sample
 };
 // p == nullptr: directional lights (lights.l = unit direction towards the light, lights.w = albedo/pi * irradiance);
 // p != nullptr: point lights (lights.l = position, lights.w = albedo/pi * intensity), grad_p is then written too

@@ -617,12 +617,13 @@ def _f3(x):
 
 class _DirectLightingOp(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, sh_n, d, t, lights, albedo, spp, vis):
+    def forward(ctx, sh_n, d, t, lights, albedo, spp, vis, weight):
         n = sh_n.shape[1]
         K = lights.shape[0]
         sn, sn_p = _f3(sh_n)
         dd, dd_p = _f3(d)
         tt = t.to(dtype=torch.float32).contiguous()
+        ww = weight.detach().to(dtype=torch.float32).contiguous() if weight is not None else None
         L = (_capi.hf_dir_light_t * K)()
         lh = lights.detach().cpu().tolist()
         for k in range(K):
@@ -633,37 +634,42 @@ class _DirectLightingOp(torch.autograd.Function):
             vis_p = (C.c_void_p * K)(*[vis[k].data_ptr() for k in range(K)])
         image = torch.empty((K, n // spp), dtype=torch.float32, device=sh_n.device)
         stream = torch.cuda.current_stream(sh_n.device).cuda_stream
-        check(_capi.lib().hf_direct_lighting(n, spp, C.byref(sn_p), C.byref(dd_p), tt.data_ptr(), K, L, albedo,
-                                             vis_p, image.data_ptr(), stream))
-        ctx.save_for_backward(sn, dd, tt)
-        ctx.misc = (L, K, albedo, spp, vis, vis_p)
+        check(_capi.lib().hf_direct_lighting_weighted(n, spp, C.byref(sn_p), C.byref(dd_p), tt.data_ptr(),
+                                                      ww.data_ptr() if ww is not None else None, K, L, albedo,
+                                                      vis_p, image.data_ptr(), stream))
+        ctx.save_for_backward(sn, dd, tt, *([ww] if ww is not None else []))
+        ctx.misc = (L, K, albedo, spp, vis, vis_p, ww is not None)
         return image
 
     @staticmethod
     def backward(ctx, grad_image):
-        sn, dd, tt = ctx.saved_tensors
-        L, K, albedo, spp, vis, vis_p = ctx.misc
+        L, K, albedo, spp, vis, vis_p, weighted = ctx.misc
+        sn, dd, tt = ctx.saved_tensors[:3]
+        ww = ctx.saved_tensors[3] if weighted else None
         n = sn.shape[1]
         _, sn_p = _f3(sn)
         _, dd_p = _f3(dd)
         gi = grad_image.to(dtype=torch.float32).contiguous()
         gn = torch.empty_like(sn)
+        gw = torch.empty(n, dtype=torch.float32, device=sn.device) if weighted else None
         gn_p = (C.c_void_p * 3)(gn[0].data_ptr(), gn[1].data_ptr(), gn[2].data_ptr())
         stream = torch.cuda.current_stream(sn.device).cuda_stream
-        check(_capi.lib().hf_direct_lighting_adjoint(n, spp, C.byref(sn_p), C.byref(dd_p), tt.data_ptr(), K, L, albedo,
-                                                     vis_p, gi.data_ptr(), C.byref(gn_p), stream))
-        return gn, None, None, None, None, None, None
+        check(_capi.lib().hf_direct_lighting_weighted_adjoint(
+            n, spp, C.byref(sn_p), C.byref(dd_p), tt.data_ptr(), ww.data_ptr() if weighted else None, K, L, albedo,
+            vis_p, gi.data_ptr(), C.byref(gn_p), gw.data_ptr() if weighted else None, stream))
+        return gn, None, None, None, None, None, None, gw
 
 
-def direct_lighting(si, ray, lights, albedo=1.0, spp=1, vis=None):
+def direct_lighting(si, ray, lights, albedo=1.0, spp=1, vis=None, weight=None):
     """Diffuse direct lighting under directional lights + box-filter film, on the wavefront
     (``hf_direct_lighting``; the emitter-sampling term of direct_reparam.py:149-175 with diffuse.cpp:135-140).
     ``lights``: [K, 4] tensor of (unit direction towards the light, irradiance); ``vis``: optional [K, n] uint8,
-    0 = shadowed (``~shape.ray_test(shadow ray)``).  Returns the [K, n // spp] images; differentiable with
-    respect to ``si.sh_frame.n`` (``hf_direct_lighting_adjoint``), which carries the gradient on to
-    ``hf_adjoint`` and the heights."""
+    0 = shadowed (``~shape.ray_test(shadow ray)``); ``weight``: optional [n] per-sample factor -- the determinant of a
+    reparameterised camera ray (direct_reparam.py:164-180), differentiable.  Returns the [K, n // spp] images;
+    differentiable with respect to ``si.sh_frame.n`` (``hf_direct_lighting_adjoint``), which carries the gradient on
+    to ``hf_adjoint`` and the heights, and to ``weight``."""
     lights = torch.as_tensor(lights, dtype=torch.float32)
-    return _DirectLightingOp.apply(si.sh_frame.n, ray.d, si.t, lights, float(albedo), int(spp), vis)
+    return _DirectLightingOp.apply(si.sh_frame.n, ray.d, si.t, lights, float(albedo), int(spp), vis, weight)
 
 
 class _PointLightingOp(torch.autograd.Function):

@@ -93,3 +93,89 @@ def test_cxx_host_drives_the_abi_without_python(hf):
     out = subprocess.run([exe, "64", "96", "4", "60"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "mean |h - h*|" in out.stdout
+
+
+def test_sharded_loop_equals_the_unsharded_loop(hf):
+    """configs[4] as a sharded program: the film cut into the 32x32-pixel tiles of partition_tiles, V "virtual ranks"
+    rendered one after the other on this device (under torchrun each rank renders its own list and the gradient
+    texture is all-reduced: the sum the backward passes accumulate here).
+    (1) At the same heights the summed shard gradient equals the unsharded gradient (1e-5 relative L2, the order of
+    the float atomics).  (2) The loop: loss and height trajectory of the first 10 Adam steps agree to 1e-4 / 2e-4 (measured: 1e-7 .. 5e-6 / 3e-5);
+    later a hit that flips to a neighbouring triangle in one of the runs (heights differing in the fifth digit) sends
+    the two trajectories apart texel by texel, as it does for two runs of the reference -- not compared."""
+    import math
+    import torch
+    import inverse_heights
+    # (1) gradient at fixed heights
+    grid, film, spp = 64, 96, 4
+    L = inverse_heights.LIGHTS
+    lights = torch.cat([L / L.norm(dim=1, keepdim=True), torch.full((len(L), 1), math.pi)], 1)
+    target = hf.Heightfield(heightfield=hf.workload.sine_heights(grid, grid, device="cuda"), max_height=0.5)
+    cam = dict(origin=(0.6, 0.35, 2.0), target=(0.0, 0.0, 0.25), scale=(0.95, 0.95, 1.0))
+
+    def grad_of(pixel_lists):
+        shape = hf.Heightfield(heightfield=0.5 + 0.1 * hf.workload.sine_heights(grid, grid, device="cuda"), max_height=0.5)
+        shape.heightfield.requires_grad_(True)
+        total = 0.0
+        for pixels in pixel_lists:
+            rays = hf.workload.ortho_rays(film, film, spp, "cuda", pixels=pixels, **cam)
+            ray = hf.Ray3f(rays[0:3], rays[3:6], rays[6])
+            with torch.no_grad():
+                tgt = inverse_heights.render(target, ray, lights, spp)[0]
+            loss = ((inverse_heights.render(shape, ray, lights, spp)[0] - tgt) ** 2).sum() / (film * film)
+            loss.backward()
+            total += float(loss.detach())
+        return total, shape.heightfield.grad.double()
+    l1, g1 = grad_of([None])
+    l3, g3 = grad_of(hf.workload.partition_tiles(film, film, 3))
+    assert abs(l1 - l3) <= 1e-6 * abs(l1)
+    assert float(torch.linalg.norm(g1 - g3)) <= 1e-5 * float(torch.linalg.norm(g1))
+    assert float(torch.linalg.norm(g1)) > 0
+    # (2) the loop
+    kw = dict(grid=grid, film=film, spp=spp, steps=12, lr=0.02, verbose=False)
+    one, three = [], []
+    h1, _, _ = inverse_heights.run(record=one, **kw)
+    h3, _, _ = inverse_heights.run(record=three, virtual_ranks=3, **kw)
+    for k in range(10):
+        assert abs(h1[k] - h3[k]) <= 1e-4 * abs(h1[k]), (k, h1[k], h3[k])
+        assert float((one[k] - three[k]).abs().max()) <= 2e-4, k
+    assert float((one[9] - one[0]).abs().max()) > 0.05     # ... and the trajectory is not trivial
+
+
+def test_weighted_direct_lighting_equals_torch_arithmetic(hf):
+    """hf_direct_lighting's per-sample weight row (the determinant of a reparameterised camera ray,
+    direct_reparam.py:164-180): image, d/d sh_frame.n and d/d weight against the same shading written in torch."""
+    import math
+    import torch
+    h = hf.workload.sine_heights(64, 64, device="cuda")
+    shape = hf.Heightfield(heightfield=h, max_height=0.5)
+    spp = 4
+    rays = hf.workload.ortho_rays(48, 48, spp, "cuda", origin=(0.6, 0.35, 2.0), target=(0.0, 0.0, 0.25), scale=(0.95, 0.95, 1.0))
+    ray = hf.Ray3f(rays[0:3], rays[3:6], rays[6])
+    import inverse_heights
+    L = inverse_heights.LIGHTS
+    lights = torch.cat([L / L.norm(dim=1, keepdim=True), torch.full((len(L), 1), math.pi)], 1).cuda()
+    si = shape.ray_intersect(ray, hf.RayFlags.All)
+    gen = torch.Generator(device="cuda"); gen.manual_seed(5)
+    n = si.sh_frame.n.detach().clone().requires_grad_(True)
+    w = (1.0 + 0.3 * torch.randn(len(ray), device="cuda", generator=gen)).requires_grad_(True)
+    gimg = torch.randn((len(lights), len(ray) // spp), device="cuda", generator=gen)
+
+    class _Si:      # the op reads sh_frame.n and t
+        pass
+    s2 = _Si(); s2.sh_frame = _Si(); s2.sh_frame.n = n; s2.t = si.t
+    img = hf.direct_lighting(s2, ray, lights, albedo=1.0, spp=spp, weight=w)
+    (img * gimg).sum().backward()
+    gn, gw = n.grad.clone(), w.grad.clone()
+    n2 = si.sh_frame.n.detach().clone().requires_grad_(True)
+    w2 = w.detach().clone().requires_grad_(True)
+    valid = torch.isfinite(si.t)
+    facing = valid & (-(n2 * ray.d).sum(0) > 0)
+    cos = torch.clamp((lights[:, :3, None] * n2[None]).sum(1), min=0.0)
+    sample = torch.where(facing[None], cos * (lights[:, 3:4] / math.pi), torch.zeros_like(cos)) * w2[None]
+    ref = sample.reshape(len(lights), -1, spp).mean(2)
+    (ref * gimg).sum().backward()
+    assert torch.allclose(img, ref, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(gn, n2.grad, rtol=1e-4, atol=1e-6)
+    assert torch.allclose(gw, w2.grad, rtol=1e-4, atol=1e-6)
+    assert float(gw.abs().max()) > 0
