@@ -76,7 +76,12 @@ enum {
     HF_RAY_FOLLOWSHAPE   = 0x80,
     HF_RAY_DETACHSHAPE   = 0x100,
     HF_RAY_ALL           = 0x2 | 0x4 | 0x8,
-    HF_RAY_ALL_NONDIFF   = 0x2 | 0x4 | 0x8 | 0x100
+    HF_RAY_ALL_NONDIFF   = 0x2 | 0x4 | 0x8 | 0x100,
+    /* libhf extension (not a Mitsuba RayFlags value; bits above the reference's): with HF_RAY_BOUNDARYTEST,
+     * boundary_test is the reference Mesh's per-triangle SDF over ALL three edges of the hit triangle
+     * (src/render/mesh.cpp:845-890, 0 on an edge .. 1 at the incentre) instead of this shape's default, the same
+     * SDF restricted to SILHOUETTE edges (a deliberate extension for heightfields) */
+    HF_RAY_BOUNDARY_ALL_EDGES = 0x10000
 };
 
 typedef struct hf_field hf_field_t; /* opaque handle: owns heights copy, min/max mips */

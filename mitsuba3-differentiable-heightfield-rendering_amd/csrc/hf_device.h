@@ -284,7 +284,9 @@ __device__ __forceinline__ void compute_si_to(const hf_dev_field &f, v3 o, v3 d,
     out.t(t);
     out.p(p);
     if (flags & 0x40u)
-        out.boundary_test(boundary_test_flat(p, P[0], dp0, dp1, silhouette_edges(f, prim, xform_vec(f.to_object, d))));
+        // 0x10000 (HF_RAY_BOUNDARY_ALL_EDGES, a libhf extension bit): the reference Mesh's per-triangle SDF over all
+        // three edges (mesh.cpp:845-890, values in [0, 1]) instead of the silhouette edges only
+        out.boundary_test(boundary_test_flat(p, P[0], dp0, dp1, (flags & 0x10000u) ? 7u : silhouette_edges(f, prim, xform_vec(f.to_object, d))));
     else
         out.boundary_test(0.f);
     v3 n = normalize3(cross3(dp0, dp1));

@@ -31,6 +31,9 @@ class RayFlags(enum.IntFlag):
     DetachShape = 0x100
     All = 0x2 | 0x4 | 0x8
     AllNonDifferentiable = 0x2 | 0x4 | 0x8 | 0x100
+    # libhf extension (include/hf.h HF_RAY_BOUNDARY_ALL_EDGES): boundary_test over all three triangle edges (the
+    # reference Mesh's semantics) instead of the silhouette edges only
+    BoundaryAllEdges = 0x10000
 
 
 class ParamFlags(enum.IntFlag):

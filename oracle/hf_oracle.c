@@ -683,7 +683,8 @@ int hfo_compute_si(const hfo_field *f, const float o[3], const float d[3], float
     if (flags & HFO_RAY_BOUNDARYTEST) {
         float od[3];
         xform_vec(f->to_object, d, od);
-        si->boundary_test = boundary_test_flat(si->p, P[0], dp0, dp1, silhouette_edges(f, prim, od));
+        /* 0x10000: the reference Mesh's per-triangle SDF over all three edges (mesh.cpp:845-890) */
+        si->boundary_test = boundary_test_flat(si->p, P[0], dp0, dp1, (flags & 0x10000u) ? 7u : silhouette_edges(f, prim, od));
     }
 
     /* finalize_surface_interaction, interaction.h:476-499 */

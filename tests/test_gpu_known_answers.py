@@ -116,3 +116,27 @@ def test_sample_tea_32_known_answers(hf):
     for k, key in enumerate(keys):
         got = struct.unpack("f", struct.pack("I", (int(b[k]) >> 9) | 0x3F800000))[0] - 1.0
         assert got == np.float32(expected[key]), key
+
+
+def test_boundary_test_all_edges_is_the_mesh_sdf(hf, oracle):
+    """HF_RAY_BOUNDARY_ALL_EDGES (libhf extension bit): boundary_test over all three edges of the hit triangle --
+    the reference Mesh's per-triangle SDF (mesh.cpp:845-890): in [0, 1] everywhere, equal to the oracle's, and
+    <= the default (silhouette edges only), which is exactly 1 on triangles without a silhouette edge."""
+    rng = np.random.default_rng(4)
+    h = rng.uniform(0, 1, (33, 21)).astype(np.float32)
+    shape = hf.Heightfield(heightfield=torch.from_numpy(h).cuda(), max_height=0.3)
+    import common
+    r = common.random_rays(20000, rng, 0.3)
+    rt = torch.from_numpy(r).cuda()
+    ray = hf.Ray3f(rt[0:3].contiguous(), rt[3:6].contiguous(), rt[6].contiguous())
+    base = int(hf.RayFlags.All) | int(hf.RayFlags.BoundaryTest)
+    si_all = shape.ray_intersect(ray, base | int(hf.RayFlags.BoundaryAllEdges))
+    si_sil = shape.ray_intersect(ray, base)
+    v = si_all.is_valid().cpu().numpy()
+    b_all, b_sil = si_all.boundary_test.cpu().numpy()[v], si_sil.boundary_test.cpu().numpy()[v]
+    assert v.sum() > 5000 and b_all.min() >= 0.0 and b_all.max() <= 1.0 + 1e-5
+    assert np.all(b_all <= b_sil + 1e-6) and (b_sil == 1.0).sum() > 100
+    f = oracle.OracleField(h, max_height=0.3)
+    t, u, vv, prim = f.ray_intersect_preliminary(r)
+    rec = f.compute_surface_interaction(r, t, u, vv, prim, base | 0x10000)
+    assert np.allclose(si_all.boundary_test.cpu().numpy()[v], rec["boundary_test"][v], rtol=1e-4, atol=1e-5)
