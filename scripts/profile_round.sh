@@ -23,5 +23,15 @@ python $R/scripts/make_traffic_json.py $OUT "$SRC" > $OUT/traffic.json
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -d $OUT/pmc_sq -o run -- python $R/scripts/prof_kernels.py --iters 1 fwd miss > $OUT/pmc_sq.log 2>&1
 python $R/scripts/rocpd_summary.py pmc $OUT/pmc_sq/run_results.db hf_trace > $OUT/pmc_sq.csv
 rm -rf $OUT/pmc_sq
+# cache behaviour of the traversal gathers: L2 (TCC) hits / misses, L1 (TCP) accesses and its read requests to L2
+rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum -d $OUT/pmc_tcc -o run -- python $R/scripts/prof_kernels.py --iters 1 fwd sec_fwd miss > $OUT/pmc_tcc.log 2>&1
+python $R/scripts/rocpd_summary.py pmc $OUT/pmc_tcc/run_results.db hf_trace > $OUT/pmc_tcc.csv
+rm -rf $OUT/pmc_tcc
+rocprofv3 --kernel-trace --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TCP_LATENCY_sum -d $OUT/pmc_tcp -o run -- python $R/scripts/prof_kernels.py --iters 1 fwd sec_fwd miss > $OUT/pmc_tcp.log 2>&1
+python $R/scripts/rocpd_summary.py pmc $OUT/pmc_tcp/run_results.db hf_trace > $OUT/pmc_tcp.csv
+rm -rf $OUT/pmc_tcp
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM SQ_INSTS_LDS -d $OUT/pmc_insts -o run -- python $R/scripts/prof_kernels.py --iters 1 fwd prelim miss adj > $OUT/pmc_insts.log 2>&1
+python $R/scripts/rocpd_summary.py pmc $OUT/pmc_insts/run_results.db hf_ > $OUT/pmc_insts.csv
+rm -rf $OUT/pmc_insts
 cd $R && python bench.py --steps 20 --warmup 3 > $OUT/bench_20steps.json
 ls -la $OUT
