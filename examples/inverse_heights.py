@@ -36,11 +36,12 @@ import hf_amd  # noqa: E402
 LIGHTS = torch.tensor([[0.5, 0.2, 0.84], [-0.5, 0.3, 0.81], [0.1, -0.6, 0.79], [0.0, 0.0, 1.0]])
 
 
-def render_reparameterized(shape, ray, lights, spp, aux=8, kappa=2e4, seed=0):
+def render_reparameterized(shape, ray, lights, spp, aux=8, kappa=2e4, seed=0, ray_index=None):
     """primary rays through reparameterize_ray; per-sample diffuse shading x determinant and the box film in
     hf_direct_lighting (weight row = the determinant); the gradient reaches the heights through hf_adjoint (shading
     normal), the auxiliary rays (reparameterised direction) and the determinant (weight gradient)"""
-    d, det = hf_amd.reparameterize_ray(shape, ray, num_rays=aux, kappa=kappa, exponent=3.0, seed=seed)
+    d, det = hf_amd.reparameterize_ray(shape, ray, num_rays=aux, kappa=kappa, exponent=3.0, seed=seed,
+                                       ray_index=ray_index)
     ray2 = hf_amd.Ray3f(ray.o, d, ray.maxt)
     si = shape.ray_intersect(ray2, hf_amd.RayFlags.All)
     valid = si.is_valid()
@@ -49,11 +50,11 @@ def render_reparameterized(shape, ray, lights, spp, aux=8, kappa=2e4, seed=0):
     return images, depth, valid
 
 
-def render(shape, ray, lights, spp, shadows=False, silhouette=False, aux=8, kappa=2e4, film=None):
+def render(shape, ray, lights, spp, shadows=False, silhouette=False, aux=8, kappa=2e4, film=None, ray_index=None):
     """film: None = box filter (pixel = mean of its samples, inside hf_direct_lighting); (positions [2, n], width,
     height) = the reference's default Gaussian reconstruction filter (hf_film_splat) on the per-sample values"""
     if silhouette:
-        return render_reparameterized(shape, ray, lights, spp, aux, kappa)
+        return render_reparameterized(shape, ray, lights, spp, aux, kappa, ray_index=ray_index)
     si = shape.ray_intersect(ray, hf_amd.RayFlags.All)
     valid = si.is_valid()
     if film is not None:
@@ -106,7 +107,8 @@ def run(grid=128, film=256, spp=1, steps=100, lr=0.02, device="cuda", verbose=Tr
         flm = (hf_amd.workload.film_positions(film, film, spp, dev, seed=seed), film, film) if gaussian_film else None
         with torch.no_grad():
             tgt_img, tgt_depth, tgt_valid = render(target, ray, lights, spp, shadows, film=flm)
-        shards.append((ray, flm, tgt_img, tgt_depth, tgt_valid))
+        rid = hf_amd.workload.ray_indices(film, film, spp, dev, pixels) if silhouette else None
+        shards.append((ray, flm, tgt_img, tgt_depth, tgt_valid, rid))
     shape = hf_amd.Heightfield(heightfield=torch.full_like(target_h, 0.5), max_height=0.5)
     shape.heightfield.requires_grad_(True)
     opt = hf_amd.Adam(shape, lr=lr)                       # hf_adam_step: optimizers.py:263-300 + params.update
@@ -116,8 +118,9 @@ def run(grid=128, film=256, spp=1, steps=100, lr=0.02, device="cuda", verbose=Tr
     for it in range(steps):
         opt.zero_grad()
         total = 0.0
-        for ray, flm, tgt_img, tgt_depth, tgt_valid in shards:    # (backward accumulates into heightfield.grad)
-            images, depth, valid = render(shape, ray, lights, spp, shadows, silhouette, aux, kappa, film=flm)
+        for ray, flm, tgt_img, tgt_depth, tgt_valid, rid in shards:    # (backward accumulates into heightfield.grad)
+            images, depth, valid = render(shape, ray, lights, spp, shadows, silhouette, aux, kappa, film=flm,
+                                          ray_index=rid)
             both = valid & tgt_valid
             # the multi-light renders only (configs[4]); mean over the pixels of the WHOLE film: shard losses add up
             loss = ((images - tgt_img) ** 2).sum() / npix_total

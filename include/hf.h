@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define HF_VERSION 1
+#define HF_VERSION 2 /* 2: hf_reparam_* take ray_id; hf_adjoint_rows, weighted lighting, hf_capture_reset */
 
 /* status codes */
 enum {
@@ -182,10 +182,14 @@ int hf_set_heights_host(hf_field_t *hf, const float *h_heights, hf_stream_t stre
  * gradient d_grad and the moment buffers d_m, d_v (zero them before step 1; `step` counts from 1), then
  * hf_set_heights(hf, d_heights).  lr_t = lr * sqrt(1 - beta2^step) / (1 - beta1^step);
  * m = beta1 m + (1-beta1) g;  v = beta2 v + (1-beta2) g^2;  h -= lr_t m / (sqrt(v) + eps);
- * mask_updates != 0 leaves h, m, v untouched where g == 0 (optimizers.py:282-285, 293-294).
+ * mask_updates: bit 0 (HF_ADAM_MASK_UPDATES) leaves h, m, v untouched where g == 0 (optimizers.py:282-285,
+ * 293-294); bit 1 (HF_ADAM_UNIFORM) selects the 'UniformAdam' variant (optimizers.py:259, 290-291): the update
+ * divides by sqrt(max over the texture of v) + eps instead of the per-texel sqrt(v) + eps (two launches).
  * The hyper-parameters are host doubles like the reference's Python scalars: the bias-correction scale is
  * evaluated in double and rounded once (optimizers.py:267-268), everything else runs in float32.
- * The 'uniform' variant (max of v) is not provided. */
+ */
+#define HF_ADAM_MASK_UPDATES 1
+#define HF_ADAM_UNIFORM 2
 int hf_adam_step(hf_field_t *hf, float *d_heights, const float *d_grad, float *d_m, float *d_v, double lr,
                  double beta1, double beta2, double eps, uint32_t step, int mask_updates, hf_stream_t stream);
 
@@ -339,16 +343,21 @@ int hf_film_splat_adjoint(size_t n, uint32_t channels, const float *pos_x, const
  * HF_RAY_ALL | HF_RAY_FOLLOWSHAPE | HF_RAY_BOUNDARYTEST (reparam.py:93-95) and the gradient of an
  * auxiliary hit reaches the heights through hf_adjoint with the same flags.
  * Random numbers: the reference draws two PCG32 floats per auxiliary ray (reparam.py:186); PCG32 lives in
- * the absent Dr.Jit, so sample (k, lane i) is sample_tea_32(seed + pair, i) (include/mitsuba/core/random.h:76-91)
- * -> two 23-bit floats, pair = k/2 with antithetic sampling (the even iteration of a pair reuses the
- * sample with omega_local.xy negated, reparam.py:83-85,188-190), else k.
+ * the absent Dr.Jit, so sample (k, ray i) is sample_tea_32(key, id_i) with key = sample_tea_32(seed, pair)[0]
+ * (include/mitsuba/core/random.h:76-91) -> two 23-bit floats, pair = k/2 with antithetic sampling (the even
+ * iteration of a pair reuses the sample with omega_local.xy negated, reparam.py:83-85,188-190), else k.
+ * id_i = i, the ray's index in the launch, or ray_id[i] (device array of n uint32, may be NULL): the index of the ray
+ * in a larger wavefront of which this launch traces a part (a rank's image tiles: index = pixel * spp + sample) -- the
+ * sharded launches then draw exactly the samples of the unsharded one (the reference seeds its sampler with the
+ * wavefront index the same way, src/render/sampler.cpp:116-130).  All four hf_reparam_* calls of one ray take the
+ * same seed and ray_id.
  *
  * hf_reparam_aux_rays: auxiliary ray k of every primary ray (o, d; d unit length): direction =
  * Frame3f(d).to_world(square_to_von_mises_fisher(sample, kappa)) (warp.h:546-583, frame.h:39-41,
  * vector.h:116-136), origin o, maxt = inf; inactive lanes get maxt = -1 (a miss). kappa > 0. */
 int hf_reparam_aux_rays(size_t n, const float *const o[3], const float *const d[3], const uint8_t *active,
-                        uint32_t k, float kappa, int antithetic, uint32_t seed, float *const aux_d[3],
-                        float *aux_maxt, hf_stream_t stream);
+                        uint32_t k, float kappa, int antithetic, uint32_t seed, const uint32_t *ray_id,
+                        float *const aux_d[3], float *aux_maxt, hf_stream_t stream);
 /* hf_reparam_weights, mode 0 (reparam.py:97-121, first loop of backward :224-256): from the auxiliary hit
  * (si_t, si_boundary_test) the harmonic weight w = (1 / (D - 1 + B))^exponent * D and its tangential
  * gradient d_w_omega; accumulates Z[n] += w, dZ[3][n] += d_w_omega.
@@ -364,7 +373,8 @@ int hf_reparam_aux_rays(size_t n, const float *const o[3], const float *const d[
  * ray.d through Frame3f(ray.d) by the host (mirror: hf_amd.reparameterize_ray). */
 int hf_reparam_weights(int mode, size_t n, const float *const o[3], const float *const d[3],
                        const uint8_t *active, uint32_t k, float kappa, float exponent, int antithetic,
-                       uint32_t seed, const float *si_t, const float *const si_p[3], const float *si_boundary_test,
+                       uint32_t seed, const uint32_t *ray_id, const float *si_t, const float *const si_p[3],
+                       const float *si_boundary_test,
                        float *Z, float *const dZ[3], const float *const grad_direction[3],
                        const float *grad_divergence, float *const grad_p[3], float *grad_t,
                        float *const grad_vd[3], hf_stream_t stream);
@@ -374,7 +384,7 @@ int hf_reparam_weights(int mode, size_t n, const float *const o[3], const float 
  * Bitwise the two-call sequence. */
 int hf_reparam_trace(const hf_field_t *hf, size_t n, const float *const o[3], const float *const d[3],
                      const uint8_t *active, uint32_t k, float kappa, int antithetic, uint32_t seed,
-                     const hf_pi_t *out_pi, const hf_si_t *out_si, hf_stream_t stream);
+                     const uint32_t *ray_id, const hf_pi_t *out_pi, const hf_si_t *out_si, hf_stream_t stream);
 /* The same backward pass in ONE kernel for the case that only the heights are differentiated (grad(ray) not wanted):
  * for every ray the weights of its num_rays samples and their sums Z, dZ (reparam.py:236-256), then for every
  * auxiliary HIT the gradient of its V_direct through the FollowShape surface interaction into grad_heights[H*W]
@@ -386,7 +396,8 @@ int hf_reparam_trace(const hf_field_t *hf, size_t n, const float *const o[3], co
  * of the float atomics.  1 <= num_rays <= 32. */
 int hf_reparam_backward(const hf_field_t *hf, size_t n, const float *const o[3], const float *const d[3],
                         const uint8_t *active, uint32_t num_rays, float kappa, float exponent, int antithetic,
-                        uint32_t seed, const hf_pi_const_t *pi, const float *si_boundary_test, size_t sample_stride,
+                        uint32_t seed, const uint32_t *ray_id, const hf_pi_const_t *pi, const float *si_boundary_test,
+                        size_t sample_stride,
                         const float *const grad_direction[3], const float *grad_divergence, float *grad_heights,
                         hf_stream_t stream);
 

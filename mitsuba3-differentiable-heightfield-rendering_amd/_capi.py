@@ -90,15 +90,15 @@ SYMBOLS = {
     "hf_film_splat_adjoint": (C.c_int, [C.c_size_t, C.c_uint32, _fp, _fp, C.c_uint32, C.c_uint32, C.c_float, _fp,
                                         C.POINTER(_fp), C.c_void_p]),
     "hf_reparam_aux_rays": (C.c_int, [C.c_size_t, C.POINTER(_fp * 3), C.POINTER(_fp * 3), _fp, C.c_uint32, C.c_float,
-                                      C.c_int, C.c_uint32, C.POINTER(_fp * 3), _fp, C.c_void_p]),
+                                      C.c_int, C.c_uint32, C.c_void_p, C.POINTER(_fp * 3), _fp, C.c_void_p]),
     "hf_reparam_weights": (C.c_int, [C.c_int, C.c_size_t, C.POINTER(_fp * 3), C.POINTER(_fp * 3), _fp, C.c_uint32,
-                                     C.c_float, C.c_float, C.c_int, C.c_uint32, _fp, C.POINTER(_fp * 3), _fp, _fp,
+                                     C.c_float, C.c_float, C.c_int, C.c_uint32, C.c_void_p, _fp, C.POINTER(_fp * 3), _fp, _fp,
                                      C.POINTER(_fp * 3), C.POINTER(_fp * 3), _fp, C.POINTER(_fp * 3), _fp,
                                      C.POINTER(_fp * 3), C.c_void_p]),
     "hf_reparam_trace": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(_fp * 3), C.POINTER(_fp * 3), _fp, C.c_uint32, C.c_float,
-                                   C.c_int, C.c_uint32, C.POINTER(hf_pi_t), C.POINTER(hf_si_t), C.c_void_p]),
+                                   C.c_int, C.c_uint32, C.c_void_p, C.POINTER(hf_pi_t), C.POINTER(hf_si_t), C.c_void_p]),
     "hf_reparam_backward": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(_fp * 3), C.POINTER(_fp * 3), _fp, C.c_uint32,
-                                      C.c_float, C.c_float, C.c_int, C.c_uint32, C.c_void_p, _fp, C.c_size_t,
+                                      C.c_float, C.c_float, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, _fp, C.c_size_t,
                                       C.POINTER(_fp * 3), _fp, _fp, C.c_void_p]),
     "hf_ray_intersect_preliminary_packet": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(_fp * 3), C.POINTER(_fp * 3),
                                                       C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(_fp * 2), C.c_void_p]),

@@ -19,6 +19,7 @@ struct hf_field {
     float4 *d_shear;    // owned sheared bounds of the fine levels
     size_t mip_nodes;
     int device;
+    uint32_t *d_misc;   // a few device words of the handle's own (the max of UniformAdam's second moments)
     hipEvent_t built;   // completion of the last hf_set_heights*
     // Ring of scratch blocks (the work counters of a launch), one slot per in-flight trace launch.  Every slot
     // carries the completion event of the launch that used it last: a launch that re-uses the slot first makes
@@ -179,6 +180,7 @@ static void release(hf_field *hf) {
     if (hf->d_heights) (void) hipFree(hf->d_heights);
     if (hf->d_mip) (void) hipFree(hf->d_mip);
     if (hf->d_shear) (void) hipFree(hf->d_shear);
+    if (hf->d_misc) (void) hipFree(hf->d_misc);
     delete hf->slot_mutex;
     free(hf);
 }
@@ -225,6 +227,7 @@ extern "C" int hf_create(const hf_desc_t *desc, hf_field_t **out) {
     hipError_t e = hipMalloc((void **) &hf->d_heights, sizeof(float) * (size_t) d.W * d.H);
     if (e == hipSuccess) e = hipMalloc((void **) &hf->d_mip, sizeof(float2) * off);
     if (e == hipSuccess) e = hipMalloc((void **) &hf->d_shear, sizeof(float4) * 3 * (hf_shear_records(top) + 1));
+    if (e == hipSuccess) e = hipMalloc((void **) &hf->d_misc, 256);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&hf->built, hipEventDisableTiming);
     for (int k = 0; k < HF_NUM_SLOTS && e == hipSuccess; ++k) {
         e = hipEventCreateWithFlags(&hf->slot_done[k], hipEventDisableTiming);
@@ -298,8 +301,10 @@ extern "C" int hf_adam_step(hf_field_t *hf, float *d_heights, const float *d_gra
     // lr_scale in double, rounded once, like the Python scalar the reference makes opaque (optimizers.py:267-268)
     const float lr_scale = (float) (sqrt(1.0 - pow(beta2, (double) step)) / (1.0 - pow(beta1, (double) step)));
     const float lr_t = (float) lr * lr_scale;
+    // mask_updates: bit 0 = mask_updates, bit 1 = the 'uniform' variant (optimizers.py:259, 290-291)
     hf_launch_adam((size_t) hf->dev.W * hf->dev.H, d_heights, d_grad, d_m, d_v, lr_t, (float) beta1, (float) beta2,
-                   (float) (1.0 - beta1), (float) (1.0 - beta2), (float) eps, mask_updates, (hipStream_t) stream);
+                   (float) (1.0 - beta1), (float) (1.0 - beta2), (float) eps, mask_updates & 1, (hipStream_t) stream,
+                   (mask_updates & 2) ? hf->d_misc : nullptr);
     HF_HIP(hipGetLastError());
     return hf_set_heights(hf, d_heights, stream);
 }
@@ -642,14 +647,14 @@ extern "C" int hf_film_splat_adjoint(size_t n, uint32_t channels, const float *p
 // ---- warped-area reparameterisation --------------------------------------------
 
 extern "C" int hf_reparam_aux_rays(size_t n, const float *const o[3], const float *const d[3], const uint8_t *active,
-                                   uint32_t k, float kappa, int antithetic, uint32_t seed, float *const aux_d[3],
-                                   float *aux_maxt, hf_stream_t stream) {
+                                   uint32_t k, float kappa, int antithetic, uint32_t seed, const uint32_t *ray_id,
+                                   float *const aux_d[3], float *aux_maxt, hf_stream_t stream) {
     if (!all3(o) || !all3(d) || !aux_d || !aux_d[0] || !aux_d[1] || !aux_d[2] || !aux_maxt)
         return fail(HF_EINVAL, "hf_reparam_aux_rays: NULL argument");
     if (!(kappa > 0.f)) return fail(HF_EINVAL, "hf_reparam_aux_rays: kappa must be > 0");
     if (n >= ((size_t) 1 << 32)) return fail(HF_EINVAL, "hf_reparam_aux_rays: more than 2^32 rays");
     hf_reparam_args a = {};
-    a.n = n; a.active = active; a.k = k; a.seed = seed; a.kappa = kappa; a.antithetic = antithetic;
+    a.n = n; a.active = active; a.k = k; a.seed = seed; a.kappa = kappa; a.antithetic = antithetic; a.ray_id = ray_id;
     for (int c = 0; c < 3; ++c) { a.o[c] = o[c]; a.d[c] = d[c]; a.aux_d[c] = aux_d[c]; }
     a.aux_maxt = aux_maxt;
     hf_launch_reparam_aux(a, (hipStream_t) stream);
@@ -659,7 +664,7 @@ extern "C" int hf_reparam_aux_rays(size_t n, const float *const o[3], const floa
 
 extern "C" int hf_reparam_weights(int mode, size_t n, const float *const o[3], const float *const d[3],
                                   const uint8_t *active, uint32_t k, float kappa, float exponent, int antithetic,
-                                  uint32_t seed, const float *si_t, const float *const si_p[3],
+                                  uint32_t seed, const uint32_t *ray_id, const float *si_t, const float *const si_p[3],
                                   const float *si_boundary_test, float *Z, float *const dZ[3],
                                   const float *const grad_direction[3], const float *grad_divergence,
                                   float *const grad_p[3], float *grad_t, float *const grad_vd[3],
@@ -674,7 +679,7 @@ extern "C" int hf_reparam_weights(int mode, size_t n, const float *const o[3], c
     if (n >= ((size_t) 1 << 32)) return fail(HF_EINVAL, "hf_reparam_weights: more than 2^32 rays");
     hf_reparam_args a = {};
     a.n = n; a.active = active; a.k = k; a.seed = seed; a.kappa = kappa; a.exponent = exponent;
-    a.antithetic = antithetic; a.mode = mode;
+    a.antithetic = antithetic; a.mode = mode; a.ray_id = ray_id;
     a.si_t = si_t; a.si_bt = si_boundary_test; a.Z = Z; a.g_div = grad_divergence; a.g_t = grad_t;
     for (int c = 0; c < 3; ++c) {
         a.o[c] = o[c]; a.d[c] = d[c]; a.dZ[c] = dZ[c];
@@ -690,7 +695,7 @@ extern "C" int hf_reparam_weights(int mode, size_t n, const float *const o[3], c
 
 extern "C" int hf_reparam_trace(const hf_field_t *hf, size_t n, const float *const o[3], const float *const d[3],
                                 const uint8_t *active, uint32_t k, float kappa, int antithetic, uint32_t seed,
-                                const hf_pi_t *out_pi, const hf_si_t *out_si, hf_stream_t stream) {
+                                const uint32_t *ray_id, const hf_pi_t *out_pi, const hf_si_t *out_si, hf_stream_t stream) {
     if (!all3(o) || !all3(d)) return fail(HF_EINVAL, "hf_reparam_trace: NULL argument");
     hf_rays_t rays; // maxt is not read for auxiliary rays (infinity); any readable array of n floats will do
     for (int c = 0; c < 3; ++c) { rays.o[c] = o[c]; rays.d[c] = d[c]; }
@@ -701,7 +706,7 @@ extern "C" int hf_reparam_trace(const hf_field_t *hf, size_t n, const float *con
     if (!(kappa > 0.f)) return fail(HF_EINVAL, "hf_reparam_trace: kappa must be > 0");
     if (n >= ((size_t) 1 << 32)) return fail(HF_EINVAL, "hf_reparam_trace: more than 2^32 rays");
     hf_reparam_args a = {};
-    a.k = k; a.seed = seed; a.kappa = kappa; a.antithetic = antithetic;
+    a.k = k; a.seed = seed; a.kappa = kappa; a.antithetic = antithetic; a.ray_id = ray_id;
     {
         slot_lease lease(hf, (hipStream_t) stream, hf_trace_scratch_bytes(n));
         if (!lease.buf) return fail(lease.code, "trace launch: %s", lease.why);
@@ -714,7 +719,7 @@ extern "C" int hf_reparam_trace(const hf_field_t *hf, size_t n, const float *con
 
 extern "C" int hf_reparam_backward(const hf_field_t *hf, size_t n, const float *const o[3], const float *const d[3],
                                    const uint8_t *active, uint32_t num_rays, float kappa, float exponent,
-                                   int antithetic, uint32_t seed, const hf_pi_const_t *pi,
+                                   int antithetic, uint32_t seed, const uint32_t *ray_id, const hf_pi_const_t *pi,
                                    const float *si_boundary_test, size_t sample_stride,
                                    const float *const grad_direction[3], const float *grad_divergence,
                                    float *grad_heights, hf_stream_t stream) {
@@ -733,6 +738,7 @@ extern "C" int hf_reparam_backward(const hf_field_t *hf, size_t n, const float *
                     hf->device);
     hf_reparam_args a = {};
     a.n = n; a.active = active; a.seed = seed; a.kappa = kappa; a.exponent = exponent; a.antithetic = antithetic;
+    a.ray_id = ray_id;
     a.si_bt = si_boundary_test; a.g_div = grad_divergence;
     for (int c = 0; c < 3; ++c) { a.o[c] = o[c]; a.d[c] = d[c]; a.g_dir[c] = grad_direction[c]; }
     hf_launch_reparam_backward(hf->dev, a, num_rays, sample_stride, pi, grad_heights, (hipStream_t) stream);

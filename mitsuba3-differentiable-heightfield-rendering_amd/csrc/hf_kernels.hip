@@ -386,11 +386,15 @@ __device__ __forceinline__ bool setup_ray(const hf_dev_field &f, float2 zr, v3 o
     r.idx = 1.0f / __builtin_fabsf(dx); r.idy = 1.0f / __builtin_fabsf(dy);
     const float reach = __builtin_fabsf(oo.x) + __builtin_fabsf(oo.y) +
                         tin * (__builtin_fabsf(od.x) + __builtin_fabsf(od.y)) + 2.f;
-    // xy margin: covers the rounding of the walk and of the triangle test itself (which grows with
-    // the distance of the origin); the anchor scheme needs 3m < 1 cell, so it is capped -- beyond
-    // ~0.28/(4.8e-7*max(hx,hy)) object units from the grid the result is no longer guaranteed to be
-    // the brute force's bit for bit (the triangle test itself is noise at that distance).
-    const float m = fminf(0.015625f + 4.8e-7f * reach * fmaxf(hx, hy), 0.3f);
+    // xy margin: covers the rounding of the walk and the NOISE OF THE TRIANGLE TEST ITSELF -- how far beside the exact
+    // ray a triangle can lie and still be reported hit by the fp32 Moeller-Trumbore arithmetic -- which grows faster
+    // than linearly with the distance of the origin (against float64 geometry and the brute force over all cells:
+    // 0.001 cell from 3 units away, up to 1.7 cells from 50 units away on needle terrain at N = 4096).  Beyond a reach
+    // of 8 units the distance term therefore grows with (reach / 8)^2 (round 3: with the linear term and a cap of 0.3
+    // cell the walk missed ~1 such hit in 10^4 rays traced from 50 units away; the walk only gets slower with m);
+    // within 8 units -- every BASELINE configuration -- the margin is what it was.  Same formula in the oracle's walk.
+    const float far = fmaxf(1.f, 0.125f * reach);
+    const float m = 0.015625f + 4.8e-7f * reach * fmaxf(hx, hy) * (far * far);
     r.mz = mz0 + 4.8e-7f * (__builtin_fabsf(oo.z) + tin * __builtin_fabsf(od.z) + zspan);
     r.gxm = gx + m; r.gxp = gx - m; r.gym = gy + m; r.gyp = gy - m;
     float thi = tout - tin;
@@ -848,8 +852,13 @@ struct hf_aux_sample {
 };
 __device__ __forceinline__ void aux_sample(const hf_reparam_args &a, size_t i, v3 d, hf_aux_sample &q) {
     const uint32_t pair = a.antithetic ? (a.k >> 1) : a.k;
-    uint32_t r0, r1;
-    tea32(a.seed + pair, (uint32_t) i, r0, r1);
+    // The stream of a sample: (seed, pair) hashed TOGETHER (added, the streams of seed s, pair p and seed s + 1,
+    // pair p - 1 were the same one), keyed by the ray's id -- its index in the launch, or ray_id[i] when the caller
+    // says which ray of a larger wavefront this is (a rank's tiles of a partitioned wavefront: the sharded launch then
+    // draws the samples of the unsharded one).
+    uint32_t key, unused, r0, r1;
+    tea32(a.seed, pair, key, unused);
+    tea32(key, a.ray_id ? a.ray_id[i] : (uint32_t) i, r0, r1);
     const float sx = (float) (r0 >> 9) * (1.0f / 8388608.0f), sy = (float) (r1 >> 9) * (1.0f / 8388608.0f);
     // warp.h:557-566
     const float syc = fmaxf(1.f - sy, 1e-6f);
@@ -923,6 +932,7 @@ struct hf_trace_args {
     uint32_t aux_on, aux_k, aux_seed;
     float aux_kappa;
     int aux_antithetic;
+    const uint32_t *aux_ray_id;
 };
 
 // member-wise copy out of the kernarg segment (constant address space)
@@ -1053,6 +1063,7 @@ __global__ __launch_bounds__(HF_BLOCK, (MODE == 2 ? HF_TRACE_WAVES_FUSED : HF_TR
             if (MODE == 2 && AUX) {
                 hf_reparam_args sa = {};
                 sa.k = ka->aux_k; sa.seed = ka->aux_seed; sa.kappa = ka->aux_kappa; sa.antithetic = ka->aux_antithetic;
+                sa.ray_id = ka->aux_ray_id;
                 hf_aux_sample q;
                 aux_sample(sa, ub + lo, d, q);
                 d = frame_to_world(q, d, q.omega);
@@ -1215,9 +1226,10 @@ void hf_launch_trace(int mode, const hf_dev_field &f, size_t n, const hf_rays_t 
     a.f = f; a.n = n; a.rays = r; a.active = active; a.pi = p; a.hit_out = hit; a.sio = sd; a.flags = flags;
     a.counter = (unsigned long long *) scratch; a.grab = grab;
     a.n_grabs = waves;
-    a.aux_on = 0u; a.aux_k = 0u; a.aux_seed = 0u; a.aux_kappa = 1.f; a.aux_antithetic = 0;
+    a.aux_on = 0u; a.aux_k = 0u; a.aux_seed = 0u; a.aux_kappa = 1.f; a.aux_antithetic = 0; a.aux_ray_id = nullptr;
     if (aux && mode == 2) {
         a.aux_on = 1u; a.aux_k = aux->k; a.aux_seed = aux->seed; a.aux_kappa = aux->kappa; a.aux_antithetic = aux->antithetic;
+        a.aux_ray_id = aux->ray_id;
     }
     if (mode == 0)
         hipLaunchKernelGGL(hf_trace_kernel<0>, grid, block, 0, stream, a);
@@ -1622,6 +1634,7 @@ struct hf_reparam_bwd_args {
     uint32_t num_rays, seed;
     float kappa, exponent;
     int antithetic;
+    const uint32_t *ray_id;
     const float *pi_t, *pi_u, *pi_v, *si_bt;
     const uint32_t *pi_prim;
     const float *g_dir[3], *g_div;
@@ -1648,6 +1661,7 @@ __global__ __launch_bounds__(HF_BLOCK, (HF_RB_TILE > 32 ? 2 : 5)) void hf_repara
     for (int k = lane; k < HF_RB_TILE * HF_RB_TILE; k += 64) acc[k] = 0.f;
     hf_reparam_args sa = {}; // what the sampling helpers read
     sa.seed = kc->a.seed; sa.kappa = kc->a.kappa; sa.exponent = kc->a.exponent; sa.antithetic = kc->a.antithetic;
+    sa.ray_id = kc->a.ray_id;
     const size_t stride = (size_t) gridDim.x * HF_BLOCK;
     const size_t n_round = (a_n + HF_BLOCK - 1) / HF_BLOCK * HF_BLOCK; // whole waves stay in the loop (ballots below)
     for (size_t i_raw = (size_t) blockIdx.x * HF_BLOCK + threadIdx.x; i_raw < n_round; i_raw += stride) {
@@ -1777,7 +1791,7 @@ void hf_launch_reparam_backward(const hf_dev_field &f, const hf_reparam_args &ra
     if (ra.n == 0) return;
     hf_reparam_bwd_args a = {};
     a.n = ra.n; a.stride = stride; a.active = ra.active; a.num_rays = num_rays; a.seed = ra.seed; a.kappa = ra.kappa;
-    a.exponent = ra.exponent; a.antithetic = ra.antithetic;
+    a.exponent = ra.exponent; a.antithetic = ra.antithetic; a.ray_id = ra.ray_id;
     for (int c = 0; c < 3; ++c) { a.o[c] = ra.o[c]; a.d[c] = ra.d[c]; a.g_dir[c] = ra.g_dir[c]; }
     a.g_div = ra.g_div; a.si_bt = ra.si_bt;
     a.pi_t = pi->t; a.pi_u = pi->prim_uv[0]; a.pi_v = pi->prim_uv[1]; a.pi_prim = pi->prim_index;
@@ -1805,9 +1819,49 @@ __global__ __launch_bounds__(HF_BLOCK) void hf_adam_kernel(size_t n, float *__re
     }
 }
 
+// 'UniformAdam' (optimizers.py:259, 290-291: the update divides by the square root of the MAXIMUM second moment of the
+// step instead of the per-element one): pass 1 updates the moments and reduces max(v) into *vmax (float bits as an
+// unsigned: v >= 0), pass 2 applies  h -= lr_t m / (sqrt(max v) + eps).
+__global__ __launch_bounds__(HF_BLOCK) void hf_adam_moments_kernel(size_t n, const float *__restrict__ g, float *__restrict__ m,
+                                                                  float *__restrict__ v, float beta1, float beta2, float c1,
+                                                                  float c2, int mask_updates, uint32_t *vmax) {
+    const size_t stride = (size_t) gridDim.x * HF_BLOCK;
+    float mx = 0.f;
+    for (size_t i = (size_t) blockIdx.x * HF_BLOCK + threadIdx.x; i < n; i += stride) {
+        const float gi = g[i];
+        float vt = v[i];
+        if (!(mask_updates && gi == 0.f)) {
+            m[i] = beta1 * m[i] + c1 * gi;
+            vt = beta2 * vt + c2 * (gi * gi);
+            v[i] = vt;
+        }
+        mx = fmaxf(mx, vt); // dr.max(v_t) runs over every entry, masked ones with their old value (:282-285, 290)
+    }
+    const uint32_t wm = wave_max_u32(__builtin_bit_cast(uint32_t, mx));
+    if ((threadIdx.x & 63u) == 0u && wm > __hip_atomic_load(vmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(vmax, wm);
+}
+__global__ __launch_bounds__(HF_BLOCK) void hf_adam_apply_uniform_kernel(size_t n, float *__restrict__ h, const float *__restrict__ g,
+                                                                        const float *__restrict__ m, float lr_t, float eps,
+                                                                        int mask_updates, const uint32_t *vmax) {
+    const float den = __builtin_sqrtf(__builtin_bit_cast(float, *vmax)) + eps;
+    const size_t stride = (size_t) gridDim.x * HF_BLOCK;
+    for (size_t i = (size_t) blockIdx.x * HF_BLOCK + threadIdx.x; i < n; i += stride) {
+        if (mask_updates && g[i] == 0.f) continue;
+        h[i] = h[i] - (lr_t * m[i]) / den;
+    }
+}
+
 void hf_launch_adam(size_t n, float *h, const float *g, float *m, float *v, float lr_t, float beta1, float beta2,
-                    float c1, float c2, float eps, int mask_updates, hipStream_t stream) {
+                    float c1, float c2, float eps, int mask_updates, hipStream_t stream, uint32_t *uniform_scratch) {
     if (n == 0) return;
+    if (uniform_scratch) {
+        (void) hipMemsetAsync(uniform_scratch, 0, sizeof(uint32_t), stream);
+        hipLaunchKernelGGL(hf_adam_moments_kernel, dim3(grid_for(n)), dim3(HF_BLOCK), 0, stream, n, g, m, v, beta1, beta2, c1, c2,
+                           mask_updates, uniform_scratch);
+        hipLaunchKernelGGL(hf_adam_apply_uniform_kernel, dim3(grid_for(n)), dim3(HF_BLOCK), 0, stream, n, h, g, m, lr_t, eps,
+                           mask_updates, uniform_scratch);
+        return;
+    }
     hipLaunchKernelGGL(hf_adam_kernel, dim3(grid_for(n)), dim3(HF_BLOCK), 0, stream, n, h, g, m, v, lr_t, beta1, beta2,
                        c1, c2, eps, mask_updates);
 }

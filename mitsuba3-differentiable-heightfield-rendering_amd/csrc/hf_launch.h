@@ -23,7 +23,8 @@ void hf_launch_adjoint(const hf_dev_field &f, size_t n, const hf_rays_t *rays, c
 // c1 = (float)(1 - beta1), c2 = (float)(1 - beta2): the differences are Python doubles in optimizers.py:279-280,
 // rounded once when they meet the float32 gradient
 void hf_launch_adam(size_t n, float *h, const float *g, float *m, float *v, float lr_t, float beta1, float beta2,
-                    float c1, float c2, float eps, int mask_updates, hipStream_t stream);
+                    float c1, float c2, float eps, int mask_updates, hipStream_t stream,
+                    uint32_t *uniform_scratch = nullptr); // non-NULL: the UniformAdam variant (one device word of scratch)
 struct hf_lights_dev {
     float l[HF_MAX_LIGHTS][3];
     float w[HF_MAX_LIGHTS]; // albedo/pi * irradiance
@@ -56,6 +57,7 @@ struct hf_reparam_args {
     const float *o[3], *d[3];
     const uint8_t *active;
     uint32_t k, seed;
+    const uint32_t *ray_id;                           // optional: the id of ray i in the sample streams (NULL: i)
     float kappa, exponent;
     int antithetic, mode;
     float *aux_d[3], *aux_maxt;                       // aux-ray generation

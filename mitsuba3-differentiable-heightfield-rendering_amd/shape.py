@@ -573,12 +573,12 @@ class Adam:
     (src/python/python/ad/optimizers.py:204-310) + ``params.update()`` (util.py:185-232):
     ``step()`` runs ``hf_adam_step`` -- the update of the parameter tensor in place and the rebuild
     of the shape's acceleration data -- in one call on the current stream.  State (m, v, t) lives here,
-    like ``Optimizer.state`` / ``Adam.t``.  The 'uniform' variant is not provided."""
+    like ``Optimizer.state`` / ``Adam.t``.  ``uniform``: the 'UniformAdam' variant (optimizers.py:259, 290-291)."""
 
-    def __init__(self, shape, lr, beta_1=0.9, beta_2=0.999, epsilon=1e-8, mask_updates=False):
+    def __init__(self, shape, lr, beta_1=0.9, beta_2=0.999, epsilon=1e-8, mask_updates=False, uniform=False):
         assert 0 <= beta_1 < 1 and 0 <= beta_2 < 1 and lr > 0 and epsilon > 0  # optimizers.py:248-249
         self.shape, self.lr, self.beta_1, self.beta_2, self.epsilon = shape, lr, beta_1, beta_2, epsilon
-        self.mask_updates = mask_updates
+        self.mask_updates, self.uniform = mask_updates, uniform
         self.reset()
 
     def reset(self):
@@ -606,7 +606,7 @@ class Adam:
         stream = torch.cuda.current_stream(h.device).cuda_stream
         check(_capi.lib().hf_adam_step(self.shape._h, h.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(),
                                        self.lr, self.beta_1, self.beta_2, self.epsilon, self.t,
-                                       1 if self.mask_updates else 0, stream))
+                                       (1 if self.mask_updates else 0) | (2 if self.uniform else 0), stream))
         self.shape._heights_keepalive = h
         self.shape._heights_version += 1
         self.shape.mark_dirty()
@@ -791,10 +791,10 @@ class _ReparameterizeOp(torch.autograd.Function):
     accumulates grad(ray.o), grad(ray.d) over the auxiliary samples)."""
 
     @staticmethod
-    def forward(ctx, heightfield, ray_o, ray_d, shape, num_rays, kappa, exponent, antithetic, seed, active):
+    def forward(ctx, heightfield, ray_o, ray_d, shape, num_rays, kappa, exponent, antithetic, seed, active, ray_index=None):
         ctx.shape = shape
         ctx.save_for_backward(ray_o, ray_d)
-        ctx.cfg = (int(num_rays), float(kappa), float(exponent), bool(antithetic), int(seed), active)
+        ctx.cfg = (int(num_rays), float(kappa), float(exponent), bool(antithetic), int(seed), active, ray_index)
         n = ray_o.shape[1]
         return ray_d.detach().clone(), torch.ones(n, dtype=torch.float32, device=ray_o.device)
 
@@ -802,7 +802,8 @@ class _ReparameterizeOp(torch.autograd.Function):
     def backward(ctx, grad_direction, grad_divergence):
         shape = ctx.shape
         ray_o, ray_d = ctx.saved_tensors
-        num_rays, kappa, exponent, antithetic, seed, active = ctx.cfg
+        num_rays, kappa, exponent, antithetic, seed, active, ray_index = ctx.cfg
+        rid_p = ray_index.data_ptr() if ray_index is not None else None
         need_h, need_o, need_d = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
         ray_grads = need_o or need_d
         L = _capi.lib()
@@ -852,13 +853,13 @@ class _ReparameterizeOp(torch.autograd.Function):
             return rows, si_s, pi_s
 
         def aux(k):
-            check(L.hf_reparam_aux_rays(n, C.byref(o_p), C.byref(d_p), act_p, k, kappa, int(antithetic), seed,
+            check(L.hf_reparam_aux_rays(n, C.byref(o_p), C.byref(d_p), act_p, k, kappa, int(antithetic), seed, rid_p,
                                         C.byref(ad_p), aux_maxt.data_ptr(), stream))
 
         def trace(k, buf):
             rows, si_s, pi_s = structs(buf)
             if fused:   # auxiliary ray generated inside the trace kernel
-                check(L.hf_reparam_trace(shape._h, n, C.byref(o_p), C.byref(d_p), act_p, k, kappa, int(antithetic), seed,
+                check(L.hf_reparam_trace(shape._h, n, C.byref(o_p), C.byref(d_p), act_p, k, kappa, int(antithetic), seed, rid_p,
                                          C.byref(pi_s), C.byref(si_s), stream))
                 return
             aux(k)
@@ -868,7 +869,7 @@ class _ReparameterizeOp(torch.autograd.Function):
             rows = _rows(buf, n)
             sp_p = (C.c_void_p * 3)(*rows[1:4])
             check(L.hf_reparam_weights(mode, n, C.byref(o_p), C.byref(d_p), act_p, k, kappa, exponent, int(antithetic),
-                                       seed, rows[0], C.byref(sp_p), rows[4], Z.data_ptr(), C.byref(dZ_p), C.byref(gd_p),
+                                       seed, rid_p, rows[0], C.byref(sp_p), rows[4], Z.data_ptr(), C.byref(dZ_p), C.byref(gd_p),
                                        gdiv.data_ptr(), C.byref(gp_p), g_t.data_ptr(),
                                        C.byref(gvd_p) if (ray_grads and mode == 1) else None, stream))
 
@@ -880,7 +881,7 @@ class _ReparameterizeOp(torch.autograd.Function):
         if fused and need_h:
             rows, si_s, pi_s = structs(bufs[0])   # sample k: the same rows of store[k], 9 n floats further on
             check(L.hf_reparam_backward(shape._h, n, C.byref(o_p), C.byref(d_p), act_p, num_rays, kappa, exponent,
-                                        int(antithetic), seed, C.byref(pi_s), rows[4], 9 * n, C.byref(gd_p),
+                                        int(antithetic), seed, rid_p, C.byref(pi_s), rows[4], 9 * n, C.byref(gd_p),
                                         gdiv.data_ptr(), grad_h.data_ptr(), stream))
         for k in range(0 if fused else num_rays):   # the same, per-sample kernels (ray gradients wanted / hits not kept)
             buf = bufs[k if keep else 0]
@@ -914,15 +915,25 @@ class _ReparameterizeOp(torch.autograd.Function):
         if gh.shape != shape.heightfield.shape:
             gh = gh.reshape(shape.heightfield.shape)
         return ((gh if need_h else None), (grad_o if need_o else None), (grad_d if need_d else None),
-                None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None)
 
 
-def reparameterize_ray(shape, ray, num_rays=4, kappa=1e5, exponent=3.0, antithetic=False, seed=0, active=None):
+def reparameterize_ray(shape, ray, num_rays=4, kappa=1e5, exponent=3.0, antithetic=False, seed=0, active=None,
+                       ray_index=None):
     """``mitsuba.ad.reparameterize_ray`` (reparam.py:336-420) for a scene made of this heightfield: returns
     ``(direction, det)`` = ``(ray.d, 1)`` -- the reparameterisation is the identity in primal mode, exactly as in
     the reference (reparam.py:139-155) -- whose gradients flow into ``shape.heightfield`` and into ``ray.o`` /
     ``ray.d`` (when those require grad) through ``num_rays`` auxiliary rays per ray (von Mises-Fisher around
     ``ray.d``, harmonic weights from ``si.boundary_test``, hits followed with ``RayFlags.FollowShape``).
-    ``ray.d`` must be unit length.  PCG32 is replaced by sample_tea_32(seed, ...) (include/hf.h)."""
+    ``ray.d`` must be unit length.  PCG32 is replaced by sample_tea_32 keyed on (seed, pair, ray id) (include/hf.h);
+    ``ray_index`` (int32/uint32 device tensor, one id per ray, e.g. the global pixel index) makes the samples of a
+    ray independent of its position in the batch, so a partitioned render draws the same auxiliary rays as the
+    unpartitioned one.  Without it the id is the position in the batch."""
+    if ray_index is not None:
+        if ray_index.dtype not in (torch.int32, torch.uint32) or ray_index.numel() != ray.o.shape[1]:
+            raise ValueError("ray_index must be an int32/uint32 tensor with one id per ray")
+        if ray_index.device != ray.o.device:
+            raise ValueError("ray_index must live on the rays' device")
+        ray_index = ray_index.contiguous()
     return _ReparameterizeOp.apply(shape.heightfield, ray.o, ray.d, shape, num_rays, kappa, exponent, antithetic, seed,
-                                   active)
+                                   active, ray_index)

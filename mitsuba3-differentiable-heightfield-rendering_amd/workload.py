@@ -111,6 +111,17 @@ def ortho_rays(film_w, film_h, spp, device, start=0, count=None, seed=0,
     return out
 
 
+def ray_indices(film_w, film_h, spp, device, pixels=None):
+    """Index in the FULL W*H*spp wavefront of every ray of ortho_rays(film_w, film_h, spp, ..., pixels) as an int32
+    tensor: the `ray_index` of reparameterize_ray / the `ray_id` of hf_reparam_*, so that a rank's tiles draw the
+    auxiliary samples the unpartitioned wavefront draws for the same rays."""
+    if pixels is None:
+        return torch.arange(film_w * film_h * spp, dtype=torch.int32, device=device)
+    pixels = pixels.to(device=device, dtype=torch.int64)
+    idx = torch.arange(int(pixels.numel()) * spp, dtype=torch.int64, device=device)
+    return (pixels[idx // spp] * spp + idx % spp).to(torch.int32)
+
+
 def film_positions(film_w, film_h, spp, device, seed=0, pixels=None):
     """Film positions (pixel units, [2, n] float32) of the samples of ortho_rays(film_w, film_h, spp, ..., seed, pixels):
     pixel index + the same jitter -- what a reconstruction filter other than the box needs (hf_film_splat)."""

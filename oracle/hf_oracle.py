@@ -234,13 +234,14 @@ def sample_tea_32(v0, v1, rounds=4):
     return int(out[0]), int(out[1])
 
 
-def adam_step(h, g, m, v, lr, beta1=0.9, beta2=0.999, eps=1e-8, step=1, mask_updates=False):
+def adam_step(h, g, m, v, lr, beta1=0.9, beta2=0.999, eps=1e-8, step=1, mask_updates=False, uniform=False):
     """One Adam step on the height texture, restating mitsuba.ad.Adam.step
     (src/python/python/ad/optimizers.py:263-300) in float32 with one rounding per operation:
     lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t)   (scale in double, rounded once, :267-268)
     m = beta1 m + (1 - beta1) g;  v = beta2 v + (1 - beta2) g^2   (:279-281)
     h = h - lr_t m / (sqrt(v) + eps)                               (:290-295)
-    mask_updates: entries with g == 0 keep h, m, v (:282-285, 293-294).  Returns (h, m, v) as new arrays."""
+    mask_updates: entries with g == 0 keep h, m, v (:282-285, 293-294); uniform: the update divides by
+    sqrt(max(v_t)) + eps, the maximum over all entries after the mask (:290-291).  Returns (h, m, v) as new arrays."""
     f = np.float32
     h, g, m, v = (np.asarray(a, f) for a in (h, g, m, v))
     lr_scale = f(np.sqrt(1.0 - float(beta2) ** int(step)) / (1.0 - float(beta1) ** int(step)))
@@ -249,10 +250,11 @@ def adam_step(h, g, m, v, lr, beta1=0.9, beta2=0.999, eps=1e-8, step=1, mask_upd
     c1, c2 = f(1.0 - float(beta1)), f(1.0 - float(beta2))   # Python doubles in the reference, rounded once
     mt = (b1 * m + c1 * g).astype(f)
     vt = (b2 * v + c2 * (g * g).astype(f)).astype(f)
-    hn = (h - ((lr_t * mt).astype(f) / (np.sqrt(vt).astype(f) + e).astype(f)).astype(f)).astype(f)
-    if mask_updates:
-        z = g == 0
-        mt = np.where(z, m, mt); vt = np.where(z, v, vt); hn = np.where(z, h, hn)
+    z = (g == 0) if mask_updates else np.zeros(g.shape, bool)
+    mt = np.where(z, m, mt); vt = np.where(z, v, vt)
+    den = (np.sqrt(f(vt.max())) + e).astype(f) if uniform else (np.sqrt(vt).astype(f) + e).astype(f)
+    hn = (h - ((lr_t * mt).astype(f) / den).astype(f)).astype(f)
+    hn = np.where(z, h, hn)
     return hn, mt, vt
 
 
@@ -386,8 +388,9 @@ def film_splat_adjoint(pos, width, height, grad_image, stddev=0.5):
 # ---------------------------------------------------------------------------------------------------
 # Warped-area reparameterisation of rays for a scene that is this one shape: float64 restatement of
 # src/python/python/ad/reparam.py:10-123 (_sample_warp_field) and :151-333 (forward / backward of
-# _ReparameterizeOp).  Random numbers: sample_tea_32(seed + pair, lane) -> two 23-bit floats, the documented
-# stand-in for the PCG32 of the absent Dr.Jit (see include/hf.h).
+# _ReparameterizeOp).  Random numbers: sample_tea_32(key, ray id) with key = sample_tea_32(seed, pair)[0] -> two 23-bit
+# floats, the documented stand-in for the PCG32 of the absent Dr.Jit (see include/hf.h); ray id = the ray's index in
+# the launch unless `ray_id` names it (a rank's rays of a partitioned wavefront).
 # ---------------------------------------------------------------------------------------------------
 def _tea32_np(v0, v1, rounds=4):
     v0 = np.asarray(v0, np.uint64) & 0xFFFFFFFF; v1 = np.asarray(v1, np.uint64) & 0xFFFFFFFF
@@ -409,13 +412,29 @@ def _coordinate_system_np(n):
     return s, t
 
 
+_REPARAM_RAY_ID = [None]   # module-level: the ray ids of the current reparam_* call (set by with_ray_ids)
+
+
+class with_ray_ids:
+    """context manager: the reparam_* functions inside draw the samples of rays `ids` (uint32 [n]) instead of 0..n-1"""
+    def __init__(self, ids):
+        self.ids = None if ids is None else np.asarray(ids, np.uint64)
+    def __enter__(self):
+        self.prev = _REPARAM_RAY_ID[0]; _REPARAM_RAY_ID[0] = self.ids
+    def __exit__(self, *a):
+        _REPARAM_RAY_ID[0] = self.prev
+
+
 def reparam_aux_sample(d, k, kappa, antithetic=False, seed=0):
     """omega_local, sample.y and the frame of auxiliary ray k of every primary direction d [3,n] (float32 inputs,
     float64 maths): warp.h:557-566, reparam.py:80-90."""
     d = np.asarray(d, np.float32).astype(np.float64)
     n = d.shape[1]
     pair = (k >> 1) if antithetic else k
-    r0, r1 = _tea32_np(np.full(n, (seed + pair) & 0xFFFFFFFF, np.uint64), np.arange(n, dtype=np.uint64))
+    key, _ = _tea32_np(np.uint64(seed & 0xFFFFFFFF), np.uint64(pair))
+    ids = _REPARAM_RAY_ID[0] if _REPARAM_RAY_ID[0] is not None else np.arange(n, dtype=np.uint64)
+    assert ids.shape == (n,)
+    r0, r1 = _tea32_np(np.full(n, key, np.uint64), ids)
     f = np.float32
     sx = (np.float32(r0 >> np.uint64(9)) * f(1.0 / 8388608.0)).astype(f); sy = (np.float32(r1 >> np.uint64(9)) * f(1.0 / 8388608.0)).astype(f)
     # warp.h:557-566 in float32, one rounding per operation: 1 - cos_theta^2 cancels, so sin_theta carries the

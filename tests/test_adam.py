@@ -35,15 +35,25 @@ def test_oracle_mask_updates_freezes_unobserved_texels(oracle):
     assert np.all(hn2[z] != h[z])  # without the mask the stale momentum keeps moving them
 
 
+def test_oracle_uniform_adam_divides_by_the_largest_second_moment(oracle):
+    """optimizers.py:259, 290-291: step = lr_t m_t / (sqrt(max(v_t)) + eps): on the first step every entry moves by
+    lr g / max|g| (up to eps), the largest by lr"""
+    rng = np.random.default_rng(2)
+    h = rng.uniform(0, 1, (5, 6)).astype(np.float32)
+    g = rng.normal(size=(5, 6)).astype(np.float32)
+    hn, m, v = oracle.adam_step(h, g, np.zeros_like(h), np.zeros_like(h), lr=0.01, step=1, uniform=True)
+    assert np.allclose(h - hn, 0.01 * g / np.abs(g).max(), atol=1e-6)
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("mask_updates", [False, True])
-def test_gpu_adam_matches_oracle_bit_for_bit(hf, oracle, mask_updates):
+@pytest.mark.parametrize("mask_updates,uniform", [(False, False), (True, False), (False, True), (True, True)])
+def test_gpu_adam_matches_oracle_bit_for_bit(hf, oracle, mask_updates, uniform):
     import torch
     rng = np.random.default_rng(5)
     H, W = 37, 53
     h0 = rng.uniform(0.2, 0.8, (H, W)).astype(np.float32)
     shape = hf.Heightfield(heightfield=torch.from_numpy(h0).cuda(), max_height=0.5)
-    opt = hf.Adam(shape, lr=0.03, beta_1=0.9, beta_2=0.99, epsilon=1e-8, mask_updates=mask_updates)
+    opt = hf.Adam(shape, lr=0.03, beta_1=0.9, beta_2=0.99, epsilon=1e-8, mask_updates=mask_updates, uniform=uniform)
     h, m, v = h0.copy(), np.zeros_like(h0), np.zeros_like(h0)
     o = torch.tensor([[0.1], [-0.2], [2.0]], device="cuda"); d = torch.tensor([[0.0], [0.0], [-1.0]], device="cuda")
     t_prev = None
@@ -52,7 +62,7 @@ def test_gpu_adam_matches_oracle_bit_for_bit(hf, oracle, mask_updates):
         g[rng.uniform(size=(H, W)) < 0.3] = 0.0
         shape.heightfield.grad = torch.from_numpy(g).cuda()
         opt.step()
-        h, m, v = oracle.adam_step(h, g, m, v, 0.03, 0.9, 0.99, 1e-8, step, mask_updates)
+        h, m, v = oracle.adam_step(h, g, m, v, 0.03, 0.9, 0.99, 1e-8, step, mask_updates, uniform)
         assert np.array_equal(shape.heightfield.detach().cpu().numpy(), h), f"heights differ at step {step}"
         assert np.array_equal(opt.state[0].cpu().numpy(), m) and np.array_equal(opt.state[1].cpu().numpy(), v)
         # the step also rebuilt the acceleration data: the trace sees the new surface

@@ -95,3 +95,35 @@ def test_mixed_rays_equal_band_brute_force(hf, oracle, terrain):
     shape = hf.Heightfield(heightfield=torch.from_numpy(h), max_height=mh)
     f = oracle.OracleField(h, max_height=mh)
     _check(hf, shape, f, mixed_rays(rng, 1 << 17, mh))
+
+
+def test_far_origin_needle_regression_on_the_gpu(hf, oracle):
+    """the round-3 fuzz find (tests/test_oracle_band.py::test_far_origin_needle_regression) and its regime through the
+    HIP kernels: the single ray, and 40 000 rays from 50 units away onto 129^2 white-noise heights against the brute
+    force over ALL cells"""
+    from test_oracle_band import _fuzz_scene
+    h, mh, tw = _fuzz_scene(78, 359)
+    f = oracle.OracleField(h, max_height=mh, to_world=tw)
+    shape = hf.Heightfield(heightfield=torch.from_numpy(h), max_height=mh, to_world=torch.from_numpy(tw))
+    r = np.array([[26.356414794921875, -7.695851802825928, 5.930713653564453,
+                   -0.9977114200592041, 0.2779437005519867, -0.2164042592048645, np.inf]], np.float32).T
+    rr = np.repeat(r, 64, 1)
+    rt = torch.from_numpy(rr).cuda()
+    pi = shape.ray_intersect_preliminary(hf.Ray3f(rt[0:3].contiguous(), rt[3:6].contiguous(), rt[6].contiguous()))
+    t, u, v, prim = f.ray_intersect_preliminary(r, naive=True, nthreads=16)
+    assert int(prim[0]) == 8133 and np.all(pi.prim_index.cpu().numpy().view(np.uint32) == 8133)
+    assert np.all(pi.t.cpu().numpy() == t[0])
+    rng = np.random.default_rng(12)
+    N, mhn, dist, n = 129, 1.0, 50.0, 40000
+    hn = rng.uniform(0, 1, (N, N)).astype(np.float32)
+    c = rng.uniform(-1, 1, (2, n)); dirs = rng.normal(size=(3, n))
+    dirs[2] = -np.abs(dirs[2]) * rng.uniform(0.05, 1.0, n); dirs /= np.linalg.norm(dirs, axis=0)
+    o = np.concatenate([c, np.full((1, n), mhn * 0.5)]) - dirs * dist
+    rays = np.concatenate([o, dirs, np.full((1, n), np.inf)]).astype(np.float32)
+    fn = oracle.OracleField(hn, max_height=mhn)
+    sn = hf.Heightfield(heightfield=torch.from_numpy(hn), max_height=mhn)
+    rt = torch.from_numpy(rays).cuda()
+    pi = sn.ray_intersect_preliminary(hf.Ray3f(rt[0:3].contiguous(), rt[3:6].contiguous(), rt[6].contiguous()))
+    t, u, v, prim = fn.ray_intersect_preliminary(rays, naive=True, nthreads=16)
+    assert np.array_equal(prim, pi.prim_index.cpu().numpy().view(np.uint32))
+    assert np.array_equal(t.view(np.uint32), pi.t.cpu().numpy().view(np.uint32))

@@ -113,7 +113,7 @@ def test_sharded_loop_equals_the_unsharded_loop(hf):
     target = hf.Heightfield(heightfield=hf.workload.sine_heights(grid, grid, device="cuda"), max_height=0.5)
     cam = dict(origin=(0.6, 0.35, 2.0), target=(0.0, 0.0, 0.25), scale=(0.95, 0.95, 1.0))
 
-    def grad_of(pixel_lists):
+    def grad_of(pixel_lists, silhouette=False):
         shape = hf.Heightfield(heightfield=0.5 + 0.1 * hf.workload.sine_heights(grid, grid, device="cuda"), max_height=0.5)
         shape.heightfield.requires_grad_(True)
         total = 0.0
@@ -122,7 +122,9 @@ def test_sharded_loop_equals_the_unsharded_loop(hf):
             ray = hf.Ray3f(rays[0:3], rays[3:6], rays[6])
             with torch.no_grad():
                 tgt = inverse_heights.render(target, ray, lights, spp)[0]
-            loss = ((inverse_heights.render(shape, ray, lights, spp)[0] - tgt) ** 2).sum() / (film * film)
+            rid = hf.workload.ray_indices(film, film, spp, "cuda", pixels) if silhouette else None
+            img = inverse_heights.render(shape, ray, lights, spp, silhouette=silhouette, aux=4, ray_index=rid)[0]
+            loss = ((img - tgt) ** 2).sum() / (film * film)
             loss.backward()
             total += float(loss.detach())
         return total, shape.heightfield.grad.double()
@@ -131,6 +133,13 @@ def test_sharded_loop_equals_the_unsharded_loop(hf):
     assert abs(l1 - l3) <= 1e-6 * abs(l1)
     assert float(torch.linalg.norm(g1 - g3)) <= 1e-5 * float(torch.linalg.norm(g1))
     assert float(torch.linalg.norm(g1)) > 0
+    # ... and with the reparameterised primary rays (--silhouette): the auxiliary samples follow the ray's index in
+    # the full wavefront (ray_index), not its place in the shard, so the sharded estimate is the SAME estimate
+    ls1, gs1 = grad_of([None], silhouette=True)
+    ls3, gs3 = grad_of(hf.workload.partition_tiles(film, film, 3), silhouette=True)
+    assert abs(ls1 - ls3) <= 1e-6 * abs(ls1)
+    assert float(torch.linalg.norm(gs1 - gs3)) <= 1e-5 * float(torch.linalg.norm(gs1))
+    assert float(torch.linalg.norm(gs1 - g1)) > 1e-3 * float(torch.linalg.norm(g1))   # the boundary term is there
     # (2) the loop
     kw = dict(grid=grid, film=film, spp=spp, steps=12, lr=0.02, verbose=False)
     one, three = [], []

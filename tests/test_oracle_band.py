@@ -94,3 +94,49 @@ def test_hierarchical_walk_equals_band_on_rough_terrain():
     f = O.OracleField(rng.uniform(0, 1, (N, N)).astype(np.float32), max_height=0.05)
     r = mixed_rays(rng, 40000, 0.05)
     _same(f.ray_intersect_preliminary(r, nthreads=NT), f.ray_intersect_preliminary(r, band=True, nthreads=NT))
+
+
+def _fuzz_scene(seed0, sc, maxdim=3000.0):
+    """the scene tests/tools/fuzz_parity.py builds for (seed0, sc): heights, max_height, to_world"""
+    rng = np.random.default_rng(seed0 * 100003 + sc)
+    W, H = (int(np.exp(rng.uniform(np.log(2), np.log(maxdim)))) for _ in range(2))
+    kind = rng.choice(["rand", "sine", "stairs", "flat", "steep", "ridge"])
+    assert kind == "rand"
+    h = common.heights(kind, W, H, rng)
+    mh = float(np.exp(rng.uniform(np.log(1e-3), np.log(10.0))))
+    tw = common.affine(int(rng.integers(1 << 30))) if rng.uniform() < 0.5 else None
+    return h, mh, tw
+
+
+def test_far_origin_needle_regression():
+    """Round-3 fuzz find (FUZZ_MAXDIM=3000, seed 78, scene 359: 285 x 301 white-noise heights, affine to_world, origin 27
+    units from the grid): the fp32 triangle test reports a hit in a cell the exact ray passes 0.021 cell beside -- the
+    noise of the test itself at that distance -- and the walks' xy margin (then linear in the distance: 0.0205 cell)
+    missed it; the brute force over all cells and the band brute force had it.  The margin now grows with
+    (reach / 8)^2 beyond 8 units (oracle walk and HIP kernel alike)."""
+    h, mh, tw = _fuzz_scene(78, 359)
+    assert h.shape == (301, 285) and tw is not None
+    f = O.OracleField(h, max_height=mh, to_world=tw)
+    r = np.array([[26.356414794921875, -7.695851802825928, 5.930713653564453,
+                   -0.9977114200592041, 0.2779437005519867, -0.2164042592048645, np.inf]], np.float32).T
+    naive = f.ray_intersect_preliminary(r, naive=True, nthreads=NT)
+    assert int(naive[3][0]) == 8133
+    _same(f.ray_intersect_preliminary(r, nthreads=NT), naive)
+    _same(f.ray_intersect_preliminary(r, band=True, nthreads=NT), naive)
+
+
+def test_far_origins_on_needles_against_the_full_brute_force():
+    """rays traced from 50 units away onto white-noise heights (129^2, every cell a needle): hierarchical walk == brute
+    force over ALL cells == band.  (At N = 4096 the same regime leaves ~5 rays in 10^6 where a grazing hit's fp32
+    determinant is so small that the reported hit lies more than the margin -- and more than the band's two cells --
+    beside the exact ray: DESIGN 4.1 states the domain; no BASELINE configuration is near it.)"""
+    rng = np.random.default_rng(12)
+    N, mh, dist, n = 129, 1.0, 50.0, 40000
+    f = O.OracleField(rng.uniform(0, 1, (N, N)).astype(np.float32), max_height=mh)
+    c = rng.uniform(-1, 1, (2, n)); dirs = rng.normal(size=(3, n))
+    dirs[2] = -np.abs(dirs[2]) * rng.uniform(0.05, 1.0, n); dirs /= np.linalg.norm(dirs, axis=0)
+    o = np.concatenate([c, np.full((1, n), mh * 0.5)]) - dirs * dist
+    r = np.concatenate([o, dirs, np.full((1, n), np.inf)]).astype(np.float32)
+    naive = f.ray_intersect_preliminary(r, naive=True, nthreads=NT)
+    _same(f.ray_intersect_preliminary(r, nthreads=NT), naive)
+    _same(f.ray_intersect_preliminary(r, band=True, nthreads=NT), naive)

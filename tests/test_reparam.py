@@ -153,10 +153,10 @@ def test_gpu_reparam_trace_equals_aux_rays_plus_ray_intersect(hf):
     for k, kappa, anti in [(0, 30.0, False), (3, 500.0, True), (2, 1e5, True)]:
         buf1, si1, pib1, pi1 = out()
         _capi.check(L.hf_reparam_trace(shape._h, n, C.byref(p3(ot)), C.byref(p3(dt)), act.data_ptr(), k, kappa, int(anti),
-                                       5, C.byref(pi1), C.byref(si1), None))
+                                       5, None, C.byref(pi1), C.byref(si1), None))
         ad = torch.empty_like(dt); mt = torch.empty(n, device="cuda")
         _capi.check(L.hf_reparam_aux_rays(n, C.byref(p3(ot)), C.byref(p3(dt)), act.data_ptr(), k, kappa, int(anti), 5,
-                                          C.byref(p3(ad)), mt.data_ptr(), None))
+                                          None, C.byref(p3(ad)), mt.data_ptr(), None))
         buf2, si2, pib2, pi2 = out()
         rs = shape._rays_struct(ot, ad, mt)
         _capi.check(L.hf_ray_intersect(shape._h, n, C.byref(rs), flags, None, C.byref(pi2), C.byref(si2), None))
@@ -179,11 +179,71 @@ def test_gpu_aux_rays_match_oracle(hf, oracle):
     p3 = lambda x: (C.c_void_p * 3)(x[0].data_ptr(), x[1].data_ptr(), x[2].data_ptr())
     for k, kappa, anti in [(0, 30.0, False), (3, 500.0, True), (2, 1e5, True)]:
         _capi.check(_capi.lib().hf_reparam_aux_rays(n, C.byref(p3(ot)), C.byref(p3(dt)), None, k, kappa, int(anti), 11,
-                                                    C.byref(p3(ad)), mt.data_ptr(), None))
+                                                    None, C.byref(p3(ad)), mt.data_ptr(), None))
         ref = oracle.reparam_aux_rays(o, d, k, kappa, anti, 11)
         got = ad.cpu().numpy()
         assert np.allclose(got, ref[3:6], atol=2e-6), np.abs(got - ref[3:6]).max()
         assert np.allclose(np.linalg.norm(got, axis=0), 1.0, atol=1e-5) and bool(torch.isinf(mt).all())
+    # explicit ray ids: the samples follow the id, not the position in the batch
+    ids = rng.permutation(n).astype(np.uint32) + 123456
+    idt = torch.from_numpy(ids.view(np.int32)).cuda()
+    _capi.check(_capi.lib().hf_reparam_aux_rays(n, C.byref(p3(ot)), C.byref(p3(dt)), None, 1, 200.0, 0, 11,
+                                                idt.data_ptr(), C.byref(p3(ad)), mt.data_ptr(), None))
+    with oracle.with_ray_ids(ids):
+        ref = oracle.reparam_aux_rays(o, d, 1, 200.0, False, 11)
+    assert np.allclose(ad.cpu().numpy(), ref[3:6], atol=2e-6)
+    assert not np.allclose(ad.cpu().numpy(), oracle.reparam_aux_rays(o, d, 1, 200.0, False, 11)[3:6], atol=1e-3)
+
+
+def test_oracle_sample_stream_decorrelates_seed_and_pair(oracle):
+    """The key of a sample is tea(seed, pair): (seed, pair + 1) and (seed + 1, pair) are different streams (they were
+    the same stream when the key was seed + pair)."""
+    rng = np.random.default_rng(3)
+    _, d = _rays(2000, rng)
+    a = oracle.reparam_aux_sample(d, 1, 50.0, False, 4)[0]
+    b = oracle.reparam_aux_sample(d, 0, 50.0, False, 5)[0]
+    c = oracle.reparam_aux_sample(d, 1, 50.0, False, 4)[0]
+    assert np.array_equal(a, c) and np.abs(a - b).max() > 0.05
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fused", [True, False])
+def test_gpu_reparam_gradient_is_invariant_under_a_partition_of_the_rays(hf, oracle, fused):
+    """With ray_index the auxiliary samples of a ray do not depend on where it sits in the batch: the gradient of a
+    render split into three shuffled parts equals the gradient of the whole (up to the order of the float atomics),
+    and both equal the oracle's with the same ids."""
+    import torch
+    from hf_amd import shape as shape_mod
+    h, f = _scene(oracle, seed=5)
+    rng = np.random.default_rng(6)
+    n = 6000
+    o, d = _rays(n, rng)
+    ids = (rng.permutation(1 << 20)[:n]).astype(np.uint32)
+    gd = rng.normal(size=(3, n)).astype(np.float32); gdiv = rng.normal(size=n).astype(np.float32)
+    need_ray_grads = not fused
+
+    def grad(parts):
+        shape = hf.Heightfield(heightfield=torch.from_numpy(h).cuda(), max_height=0.5)
+        shape.heightfield.requires_grad_(True)
+        loss = 0
+        for sel in parts:
+            oo = torch.from_numpy(o[:, sel]).cuda().requires_grad_(need_ray_grads)
+            ray = hf.Ray3f(oo, torch.from_numpy(d[:, sel]).cuda())
+            dirn, det = hf.reparameterize_ray(shape, ray, num_rays=6, kappa=300.0, antithetic=True, seed=3,
+                                              ray_index=torch.from_numpy(ids[sel].view(np.int32)).cuda())
+            loss = loss + (dirn * torch.from_numpy(gd[:, sel]).cuda()).sum() + (det * torch.from_numpy(gdiv[sel]).cuda()).sum()
+        loss.backward()
+        return shape.heightfield.grad.double().cpu().numpy()
+
+    whole = grad([np.arange(n)])
+    perm = rng.permutation(n)
+    split = grad([perm[:1000], perm[1000:4100], perm[4100:]])
+    with oracle.with_ray_ids(ids):
+        ref = oracle.reparam_backward(f, o, d, gd, gdiv, num_rays=6, kappa=300.0, exponent=3.0, antithetic=True, seed=3)
+    nr = np.linalg.norm(ref)
+    assert nr > 0
+    assert np.linalg.norm(whole - split) / nr <= 2e-6
+    assert np.linalg.norm(whole - ref) / nr <= 3e-5
 
 
 # ---- the three set-ups of src/render/tests/test_reparameterization.py:29-40 ---------------------------------
