@@ -392,9 +392,10 @@ __device__ __forceinline__ bool setup_ray(const hf_dev_field &f, float2 zr, v3 o
     // 0.001 cell from 3 units away, up to 1.7 cells from 50 units away on needle terrain at N = 4096).  Beyond a reach
     // of 8 units the distance term therefore grows with (reach / 8)^2 (round 3: with the linear term and a cap of 0.3
     // cell the walk missed ~1 such hit in 10^4 rays traced from 50 units away; the walk only gets slower with m);
-    // within 8 units -- every BASELINE configuration -- the margin is what it was.  Same formula in the oracle's walk.
+    // within 8 units -- every BASELINE configuration -- the margin is what it was.  Capped at 8 cells so that the strip
+    // a ray walks (and the time of the launch) stays bounded however far its origin.  Same formula in the oracle's walk.
     const float far = fmaxf(1.f, 0.125f * reach);
-    const float m = 0.015625f + 4.8e-7f * reach * fmaxf(hx, hy) * (far * far);
+    const float m = 0.015625f + fminf(8.f, 4.8e-7f * reach * fmaxf(hx, hy) * (far * far));
     r.mz = mz0 + 4.8e-7f * (__builtin_fabsf(oo.z) + tin * __builtin_fabsf(od.z) + zspan);
     r.gxm = gx + m; r.gxp = gx - m; r.gym = gy + m; r.gyp = gy - m;
     float thi = tout - tin;

@@ -26,7 +26,7 @@ def main(n=400000, cap=64):
     rng = np.random.default_rng(1)
     nt = min(16, os.cpu_count() or 1)
     print("N dist max_height | rays | gpu!=band walk!=band gpu!=walk | of the first %d: band==full gpu==full walk==full" % cap)
-    for N, dist, mh in [(1024, 8, 1.0), (1024, 50, 1.0), (2048, 50, 0.2), (4096, 8, 0.5), (4096, 50, 0.5), (4096, 200, 0.5)]:
+    for N, dist, mh in [(1024, 8, 1.0), (1024, 50, 1.0), (2048, 50, 0.2), (4096, 3, 0.5), (4096, 8, 0.5), (4096, 50, 0.5), (4096, 200, 0.5)]:
         h = rng.uniform(0, 1, (N, N)).astype(np.float32)
         f = O.OracleField(h, max_height=mh)
         shape = hf_amd.Heightfield(heightfield=torch.from_numpy(h).cuda(), max_height=mh)
