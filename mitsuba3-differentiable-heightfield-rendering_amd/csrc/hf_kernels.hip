@@ -261,17 +261,30 @@ void hf_launch_build_mips(const hf_dev_field &f, float2 *mip, float4 *shear, hip
 #ifdef HF_WSTATS
 // wave-level execution counters: WCOUNT(k) adds 1 per wave each time the enclosing code runs with any lane
 __device__ __forceinline__ uint32_t *wcnt_base() {
-    __shared__ uint32_t c[HF_BLOCK / 64][8];
+    __shared__ uint32_t c[HF_BLOCK / 64][16];
     return c[threadIdx.x >> 6];
 }
 #define WCOUNT(k) do { const uint64_t e_ = __ballot(true); if ((int) (threadIdx.x & 63u) == __builtin_ctzll(e_)) wcnt_base()[k]++; } while (0)
 // WLANES(k): adds the number of lanes that run the enclosing code (k = 7: low half word = visits, high = cell rounds)
 #define WLANES(k, sh) do { const uint64_t e_ = __ballot(true); if ((int) (threadIdx.x & 63u) == __builtin_ctzll(e_)) wcnt_base()[k] += (uint32_t) __builtin_popcountll(e_) << (sh); } while (0)
-__device__ __forceinline__ void wstats_reset() { if ((threadIdx.x & 63u) < 8u) wcnt_base()[threadIdx.x & 63u] = 0u; }
+__device__ __forceinline__ void wstats_reset() { if ((threadIdx.x & 63u) < 16u) wcnt_base()[threadIdx.x & 63u] = 0u; }
 // diagnostic build (scripts/wstats.py): the counters of this batch replace the hit record
+#if HF_WSTATS == 3
+// ... variant 3: c[8] = participants summed over the hand-offs of the batch, c[9] = those that took part in an earlier one
+#define WSTATS_EXPORT(alive, best) do { if (alive) { const uint32_t *c = wcnt_base(); (best).hit = true; \
+        (best).t = (float) c[5] + 4096.f * (float) c[8]; (best).u = (float) c[6] + 4096.f * (float) c[9]; \
+        (best).v = (float) c[4]; (best).prim = c[7]; } } while (0)
+#elif HF_WSTATS == 2
+// ... variant 2: how much of the walk runs when fewer than HF_WSTATS_THR lanes of the batch are still unfinished
+// (c[8] / c[9] / c[10] = visits / cell rounds / hand-offs of such "tail" hand-offs)
+#define WSTATS_EXPORT(alive, best) do { if (alive) { const uint32_t *c = wcnt_base(); (best).hit = true; \
+        (best).t = (float) c[5] + 4096.f * (float) c[8]; (best).u = (float) c[6] + 4096.f * (float) c[9]; \
+        (best).v = (float) c[4] + 4096.f * (float) c[10]; (best).prim = c[7]; } } while (0)
+#else
 #define WSTATS_EXPORT(alive, best) do { if (alive) { const uint32_t *c = wcnt_base(); (best).hit = true; \
         (best).t = (float) c[0] + 1024.f * (float) c[1] + 1048576.f * (float) c[2]; \
         (best).u = (float) c[3] + 4096.f * (float) c[4]; (best).v = (float) c[5] + 4096.f * (float) c[6]; (best).prim = c[7]; } } while (0)
+#endif
 #else
 #define WLANES(k, sh) do { } while (0)
 #define WSTATS_EXPORT(alive, best) do { } while (0)
@@ -279,6 +292,12 @@ __device__ __forceinline__ void wstats_reset() { if ((threadIdx.x & 63u) < 8u) w
 __device__ __forceinline__ void wstats_reset() { }
 #endif
 
+#ifndef HF_M0
+#define HF_M0 0.00390625f // constant part of the xy margin, cells (1/64 until round 3: see setup_ray)
+#endif
+#ifndef HF_LINE_EPS
+#define HF_LINE_EPS 1e-6f // rounding of the sheared line, per cell of the grid's side (2e-6 until round 3)
+#endif
 // per-ray traversal constants (order space, cell units, re-based at t = tin)
 struct hf_trav {
     float gxm, gxp, gym, gyp; // origin x,y  +/- the xy margin m
@@ -395,7 +414,7 @@ __device__ __forceinline__ bool setup_ray(const hf_dev_field &f, float2 zr, v3 o
     // within 8 units -- every BASELINE configuration -- the margin is what it was.  Capped at 8 cells so that the strip
     // a ray walks (and the time of the launch) stays bounded however far its origin.  Same formula in the oracle's walk.
     const float far = fmaxf(1.f, 0.125f * reach);
-    const float m = 0.015625f + fminf(8.f, 4.8e-7f * reach * fmaxf(hx, hy) * (far * far));
+    const float m = HF_M0 + fminf(8.f, 4.8e-7f * reach * fmaxf(hx, hy) * (far * far));
     r.mz = mz0 + 4.8e-7f * (__builtin_fabsf(oo.z) + tin * __builtin_fabsf(od.z) + zspan);
     r.gxm = gx + m; r.gxp = gx - m; r.gym = gy + m; r.gyp = gy - m;
     float thi = tout - tin;
@@ -420,7 +439,7 @@ __device__ __forceinline__ void shear_line(const hf_dev_field &f, const hf_ray_s
     const float dxo = __builtin_fabsf(rs.od.x) * (0.5f * (float) (f.W - 1));
     const float dyo = __builtin_fabsf(rs.od.y) * (0.5f * (float) (f.H - 1));
     dz = __builtin_fmaf(-bo, dyo, __builtin_fmaf(-ao, dxo, r.dz));
-    const float m = 0.5f * (r.gxm - r.gxp) + 2e-6f * (float) (1 << f.top);
+    const float m = 0.5f * (r.gxm - r.gxp) + HF_LINE_EPS * (float) (1 << f.top);
     mz = __builtin_fmaf(sab, m, r.mz);
 }
 
@@ -782,48 +801,93 @@ __device__ __forceinline__ bool walk_beam(const hf_dev_field &f, const hf_ray_st
         }
         uint64_t cm = __ballot(cand);
         __builtin_amdgcn_wave_barrier(); // the table is read below by every lane (same wave: LDS operations stay in order)
-        while (cm != 0ull) { // wave-uniform, front to back
-            const uint32_t k = (uint32_t) __builtin_ctzll(cm);
-            cm &= cm - 1ull;
-            WCOUNT(1);
-            const uint32_t ck = (uint32_t) __builtin_amdgcn_readlane((int) nc, (int) k), sk = sb0 + (k >> 2);
-            const uint32_t ci = xm ? sk : ck, nodej = xm ? ck : sk;
-            const float4 cbox = lds->e[k].box; // uniform address: broadcast
-            // ---- per-lane test of the node's box with the row sweep's arithmetic ----
-            const float fXc = (float) ci * S, fYc = (float) nodej * S;
-            const float xlo = (fXc - r.gxm) * r.idx, xhi = (fXc + S - r.gxp) * r.idx;
-            const float ylo = (fYc - r.gym) * r.idy, yhi = (fYc + S - r.gyp) * r.idy;
-            const float u0 = fmaxf(fmaxf(xlo, ylo), 0.f), u1 = fminf(fminf(xhi, yhi), thi);
-            const float za = __builtin_fmaf(u0, r.dz, r.gz), zb = __builtin_fmaf(u1, r.dz, r.gz);
-            const bool mine = (u0 <= u1) & (fminf(za, zb) - r.mz <= cbox.y) & (fmaxf(za, zb) + r.mz >= cbox.x);
-            if (__ballot(mine) == 0ull) {
-                // nobody overlaps this node; done when nobody can reach its slab -- or any later one -- before its t_hi
-                const float tsk = ((float) sk * S - (xm ? r.gxm : r.gym)) * (xm ? r.idx : r.idy);
-                if (__ballot(tsk <= thi) == 0ull) return true;
-                continue;
+        // One loop with ONE walk site at its end: a lane that takes a node notes it (node + children packed in one
+        // register: hf_create allows at most 2^11 nodes per side at this level) and the walk below runs at once.  The
+        // shape matters more than it should: the same sweep with the walk inside the candidate's own branch spills 13
+        // registers in the fused kernel instead of 2 (2.90-3.00 vs 2.71 ms, profiles/r03_ab/r03_v2).  Holding the nodes
+        // of a pass and walking them together when a holder wants a second one was measured too: a lane that will hit in
+        // its node still passes the box and record tests of the nodes behind it, so nearly every node flushes -- 2.1
+        // instead of 2.2 walks, 9.2 instead of 6.8 box tests, 2.80 ms.
+        uint32_t held = 0u;
+        bool done = false;
+        while (true) { // wave-uniform
+            if (cm != 0ull) {
+                const uint32_t k = (uint32_t) __builtin_ctzll(cm);
+                WCOUNT(1);
+                const uint32_t ck = (uint32_t) __builtin_amdgcn_readlane((int) nc, (int) k), sk = sb0 + (k >> 2);
+                const uint32_t ci = xm ? sk : ck, nodej = xm ? ck : sk;
+                const float4 cbox = lds->e[k].box; // uniform address: broadcast
+                // ---- per-lane test of the node's box with the row sweep's arithmetic ----
+                const float fXc = (float) ci * S, fYc = (float) nodej * S;
+                const float xlo = (fXc - r.gxm) * r.idx, xhi = (fXc + S - r.gxp) * r.idx;
+                const float ylo = (fYc - r.gym) * r.idy, yhi = (fYc + S - r.gyp) * r.idy;
+                const float u0 = fmaxf(fmaxf(xlo, ylo), 0.f), u1 = fminf(fminf(xhi, yhi), thi);
+                const float za = __builtin_fmaf(u0, r.dz, r.gz), zb = __builtin_fmaf(u1, r.dz, r.gz);
+                const bool mine = (u0 <= u1) & (fminf(za, zb) - r.mz <= cbox.y) & (fmaxf(za, zb) + r.mz >= cbox.x);
+                if (__ballot(mine) == 0ull) {
+                    // nobody overlaps this node; done when nobody can reach its slab -- or any later one -- before its t_hi
+                    const float tsk = ((float) sk * S - (xm ? r.gxm : r.gym)) * (xm ? r.idx : r.idy);
+                    cm &= cm - 1ull;
+                    if (__ballot(tsk <= thi) == 0ull) { done = true; cm = 0ull; }
+                    continue;
+                }
+                WCOUNT(2);
+                // the node's own record, for all lanes at once
+                uint32_t cur0 = 0u;
+                {
+                    const float4 pl = lds->e[k].pl, q01 = lds->e[k].q01, q23 = lds->e[k].q23;
+                    const float Sc = 0.5f * S;
+                    float gz, dz, mz;
+                    shear_line(f, rs, fx, fy, pl.x, pl.y, pl.z, pl.w, fXc + Sc, fYc + Sc, gz, dz, mz);
+                    hf_quad q;
+                    q.lo[0] = q01.x; q.hi[0] = q01.y; q.lo[1] = q01.z; q.hi[1] = q01.w;
+                    q.lo[2] = q23.x; q.hi[2] = q23.y; q.lo[3] = q23.z; q.hi[3] = q23.w;
+                    const uint32_t m4 = child_mask(r, fx, fy, fXc, fYc, Sc, q, gz, dz, mz, thi);
+                    cur0 = mine ? to_order(m4, fx, fy) : 0u;
+                }
+                cm &= cm - 1ull;
+                if (__ballot(cur0 != 0u) == 0ull) continue;
+                held = cur0 != 0u ? ci | (nodej << 12) | (cur0 << 24) : 0u; // walked at once, below
             }
-            WCOUNT(2);
-            // the node's own record, for all lanes at once
-            uint32_t cur0 = 0u;
-            {
-                const float4 pl = lds->e[k].pl, q01 = lds->e[k].q01, q23 = lds->e[k].q23;
-                const float Sc = 0.5f * S;
-                float gz, dz, mz;
-                shear_line(f, rs, fx, fy, pl.x, pl.y, pl.z, pl.w, fXc + Sc, fYc + Sc, gz, dz, mz);
-                hf_quad q;
-                q.lo[0] = q01.x; q.hi[0] = q01.y; q.lo[1] = q01.z; q.hi[1] = q01.w;
-                q.lo[2] = q23.x; q.hi[2] = q23.y; q.lo[3] = q23.z; q.hi[3] = q23.w;
-                const uint32_t m4 = child_mask(r, fx, fy, fXc, fYc, Sc, q, gz, dz, mz, thi);
-                cur0 = mine ? to_order(m4, fx, fy) : 0u;
+            // ---- walk the node just taken ----
+            if (__ballot(held != 0u) != 0ull) {
+                WCOUNT(4);
+#if defined(HF_WSTATS) && HF_WSTATS == 3
+                {   // participants of this hand-off, and how many of them took part in an earlier hand-off of the batch
+                    const uint64_t pm = __ballot(held != 0u);
+                    uint32_t *c = wcnt_base();
+                    const uint64_t prev = (uint64_t) c[11] | ((uint64_t) c[12] << 32);
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane == (uint32_t) __builtin_ctzll(pm)) {
+                        c[8] += (uint32_t) __builtin_popcountll(pm); c[9] += (uint32_t) __builtin_popcountll(pm & prev);
+                        const uint64_t nu = prev | pm; c[11] = (uint32_t) nu; c[12] = (uint32_t) (nu >> 32);
+                    }
+                }
+#endif
+#if defined(HF_WSTATS) && HF_WSTATS == 2
+                uint32_t pre_v, pre_c; bool tail;
+                {   // lanes that can still reach the node's slab: the batch's unfinished lanes
+                    const uint32_t sk = xm ? (held & 0xFFFu) : ((held >> 12) & 0xFFFu);
+                    const uint32_t sku = (uint32_t) __builtin_amdgcn_readfirstlane((int) sk);
+                    const float tsk = ((float) sku * S - (xm ? r.gxm : r.gym)) * (xm ? r.idx : r.idy);
+                    tail = __builtin_popcountll(__ballot(alive && tsk <= thi)) < HF_WSTATS_THR;
+                    pre_v = wcnt_base()[5]; pre_c = wcnt_base()[6];
+                }
+#endif
+                if (held != 0u) {
+                    const bool h = walk_subtree_from<ANY>(f, src, rs, r, rs.fx, rs.fy, lfxm, lfym, held & 0xFFFu, (held >> 12) & 0xFFFu,
+                                                          HF_SUBTREE_LEVEL, held >> 24, thi, best);
+                    if (ANY && h) thi = -1.f;
+                }
+#if defined(HF_WSTATS) && HF_WSTATS == 2
+                if (tail && lane == 0u) { uint32_t *c = wcnt_base(); c[8] += c[5] - pre_v; c[9] += c[6] - pre_c; c[10]++; }
+#endif
+                held = 0u;
+                if (ANY && __ballot(thi >= 0.f) == 0ull) return true;
             }
-            if (__ballot(cur0 != 0u) == 0ull) continue;
-            WCOUNT(4);
-            if (cur0 != 0u) {
-                const bool h = walk_subtree_from<ANY>(f, src, rs, r, rs.fx, rs.fy, lfxm, lfym, ci, nodej, HF_SUBTREE_LEVEL, cur0, thi, best);
-                if (ANY && h) thi = -1.f;
-            }
-            if (ANY && __ballot(thi >= 0.f) == 0ull) return true;
+            if (cm == 0ull) break;
         }
+        if (done) return true;
         // done when nobody can reach the first slab of the next pass before its t_hi
         const float gsm = xm ? r.gxm : r.gym, ids = xm ? r.idx : r.idy;
         const float tsn = ((float) (sb0 + HF_BEAM_ROWS) * S - gsm) * ids;

@@ -361,7 +361,7 @@ static void trace_hier(const hfo_field *f, const float o[3], const float d[3], f
     const float far = fmaxf(1.f, 0.125f * reach);
     /* capped at 8 cells: the strip the walk visits stays bounded however far the origin (a ray from 200 units away
      * at N = 4096 would otherwise ask for 120 cells each side) */
-    const float m = 0.015625f + fminf(8.f, 4.8e-7f * reach * fmaxf(hx, hy) * (far * far));
+    const float m = 0.00390625f + fminf(8.f, 4.8e-7f * reach * fmaxf(hx, hy) * (far * far));
     const float mz = mz0 + 4.8e-7f * (fabsf(oo[2]) + tin * fabsf(od[2]) + zspan);
     float thi = (tout - tin);
     thi = thi + thi * 1e-6f + 1e-30f;
