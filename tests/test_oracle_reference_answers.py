@@ -255,3 +255,27 @@ def test_heightfield_boundary_test_silhouettes(oracle):
     lower = from_side(0.3)
     assert near_crest < 0.1 and lower == 1.0, (near_crest, lower)
     assert B(ridge, [0.004, 0.03, 3.0], [0, 0, -1]) == 1.0                       # from above the crest is no silhouette
+
+
+def test_boundary_test_next_to_a_silhouette_vertex(oracle):
+    """A known limit of the silhouette-edge boundary test, pinned so that it cannot change unnoticed: a
+    triangle that touches the silhouette only at a VERTEX has no silhouette edge, so B stays 1 (the incentre value)
+    right up to that vertex, while the neighbouring triangle that owns the border edge goes to 0 there.  Hosts that
+    need the reference Mesh's SDF over all three edges (mesh.cpp:845-890, B in [0, 1], -> 0 at every vertex) set
+    HF_RAY_BOUNDARY_ALL_EDGES (0x10000)."""
+    f = oracle.OracleField(np.full((9, 9), 0.5, np.float32), 1.0)      # 8 x 8 cells of 0.25; the silhouette is the border
+    sil = oracle.RAY_ALL | oracle.RAY_BOUNDARYTEST
+    seen = set()
+    for dy in (1e-4, -1e-4):                                            # either side of the grid line y = -0.25, 0.001 from x = 1
+        r = _rays([0.999, -0.25 + dy, 3.0], [0, 0, -1])
+        t, u, v, prim = f.ray_intersect_preliminary(r)
+        assert np.isfinite(t[0]) and (prim[0] >> 1) % 8 == 7            # a cell of the last column
+        b_sil = float(f.compute_surface_interaction(r, t, u, v, prim, sil)["boundary_test"][0])
+        b_all = float(f.compute_surface_interaction(r, t, u, v, prim, sil | 0x10000)["boundary_test"][0])
+        assert 0.0 <= b_all < 0.05                                      # all edges: the vertex is on two of them
+        if prim[0] & 1:                                                 # triangle (v11, v01, v10): its right edge IS the border
+            assert b_sil < 0.05
+        else:                                                           # triangle (v00, v10, v01): touches the border at v10 only
+            assert b_sil == 1.0
+        seen.add(int(prim[0] & 1))
+    assert seen == {0, 1}
