@@ -411,8 +411,12 @@ __device__ __forceinline__ bool setup_ray(const hf_dev_field &f, float2 zr, v3 o
     // 0.001 cell from 3 units away, up to 1.7 cells from 50 units away on needle terrain at N = 4096).  Beyond a reach
     // of 8 units the distance term therefore grows with (reach / 8)^2 (round 3: with the linear term and a cap of 0.3
     // cell the walk missed ~1 such hit in 10^4 rays traced from 50 units away; the walk only gets slower with m);
-    // within 8 units -- every BASELINE configuration -- the margin is what it was.  Capped at 8 cells so that the strip
-    // a ray walks (and the time of the launch) stays bounded however far its origin.  Same formula in the oracle's walk.
+    // within 8 units -- every BASELINE configuration -- the distance term is what it was.  Capped at 8 cells so that the
+    // strip a ray walks (and the time of the launch) stays bounded however far its origin.  The constant part HF_M0 is
+    // pure slack on top of the distance term, which is never below 8 eps x (grid side) -- the rounding of the walk's own
+    // slab arithmetic; it was 1/64 cell until round 3 and fattened every sheared slab by 3x its curvature thickness on
+    // smooth terrain: at 1/256 a batch needs 4.7 instead of 5.7 cell rounds (forward -3 %, bounce rays -4 %).  Same
+    // formula in the oracle's walk; the band brute force (no margins at all) and 1.0e9 fuzz rays check that it suffices.
     const float far = fmaxf(1.f, 0.125f * reach);
     const float m = HF_M0 + fminf(8.f, 4.8e-7f * reach * fmaxf(hx, hy) * (far * far));
     r.mz = mz0 + 4.8e-7f * (__builtin_fabsf(oo.z) + tin * __builtin_fabsf(od.z) + zspan);

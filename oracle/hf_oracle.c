@@ -356,7 +356,9 @@ static void trace_hier(const hfo_field *f, const float o[3], const float d[3], f
      * brute force over ALL cells: 0.001 cell from 3 units away, 0.02 .. 1.7 cells from 50 units away on needle terrain
      * at N = 285 .. 4096).  Round 3 (a fuzz mismatch of the linear term, tests/test_oracle_band.py::
      * test_far_origin_needle_regression): beyond a reach of 8 units the distance term grows with the square of
-     * reach / 8 (the walk only gets slower); within 8 units -- every BASELINE configuration -- it is what it was. */
+     * reach / 8 (the walk only gets slower); within 8 units -- every BASELINE configuration -- it is what it was.
+     * The constant part is slack on top (1/64 cell until round 3, 1/256 since: the distance term alone is never
+     * below 8 eps x the grid's side, the rounding of the slab arithmetic). */
     const float reach = fabsf(oo[0]) + fabsf(oo[1]) + tin * (fabsf(od[0]) + fabsf(od[1])) + 2.f;
     const float far = fmaxf(1.f, 0.125f * reach);
     /* capped at 8 cells: the strip the walk visits stays bounded however far the origin (a ray from 200 units away
