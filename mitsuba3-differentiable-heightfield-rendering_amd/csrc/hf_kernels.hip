@@ -177,6 +177,13 @@ __global__ __launch_bounds__(HF_BLOCK) void hf_shear_level1_kernel(const float *
 // (a = b = c = 0, slope factor 0: w = z, and shear_line leaves the ray's z line untouched bit for bit), so that
 // the per-lane walk reads every inner node through ONE code path -- three 16-byte loads from one address.
 // Children of node (ix,iy) of level L = nodes (2ix+jx, 2iy+jy) of depth k+1 of the pyramid (L >= 2).
+// (a, b, c) = 0 and |a|+|b|+r = the largest child range r: the record of a min/max level.  r is the needle term of
+// shear_line's z margin -- a hit reported up to m cells beside the walk's ray sits up to m x (height range) above or
+// below it -- which the fitted-plane records carry too; absent children (+inf, -inf) do not count.
+__device__ __forceinline__ float4 hf_minmax_plane(float2 a, float2 b, float2 d, float2 e) {
+    const float r = fmaxf(fmaxf(fmaxf(a.y - a.x, b.y - b.x), fmaxf(d.y - d.x, e.y - e.x)), 0.f);
+    return make_float4(0.f, 0.f, 0.f, r);
+}
 __global__ __launch_bounds__(HF_BLOCK) void hf_shear_minmax_kernel(const float2 *__restrict__ child, int sh,
                                                                   float4 *__restrict__ out) {
     const int node = blockIdx.x * HF_BLOCK + threadIdx.x;
@@ -185,7 +192,7 @@ __global__ __launch_bounds__(HF_BLOCK) void hf_shear_minmax_kernel(const float2 
     const float2 *c = child + ((size_t) (2 * iy) << (sh + 1)) + 2 * ix;
     const float2 a = c[0], b = c[1], d = c[(size_t) 1 << (sh + 1)], e = c[((size_t) 1 << (sh + 1)) + 1];
     float4 *rec = out + (size_t) node * 3;
-    rec[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+    rec[0] = hf_minmax_plane(a, b, d, e);
     rec[1] = make_float4(a.x, a.y, b.x, b.y);
     rec[2] = make_float4(d.x, d.y, e.x, e.y);
 }
@@ -208,7 +215,7 @@ __global__ __launch_bounds__(1024) void hf_mip_top_kernel(float2 *__restrict__ m
             o[node] = make_float2(fminf(fminf(a.x, b.x), fminf(d.x, e.x)), fmaxf(fmaxf(a.y, b.y), fmaxf(d.y, e.y)));
             if (rec_level) {
                 float4 *rec = recs + (size_t) node * 3;
-                rec[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+                rec[0] = hf_minmax_plane(a, b, d, e);
                 rec[1] = make_float4(a.x, a.y, b.x, b.y);
                 rec[2] = make_float4(d.x, d.y, e.x, e.y);
             }
@@ -269,7 +276,14 @@ __device__ __forceinline__ uint32_t *wcnt_base() {
 #define WLANES(k, sh) do { const uint64_t e_ = __ballot(true); if ((int) (threadIdx.x & 63u) == __builtin_ctzll(e_)) wcnt_base()[k] += (uint32_t) __builtin_popcountll(e_) << (sh); } while (0)
 __device__ __forceinline__ void wstats_reset() { if ((threadIdx.x & 63u) < 16u) wcnt_base()[threadIdx.x & 63u] = 0u; }
 // diagnostic build (scripts/wstats.py): the counters of this batch replace the hit record
-#if HF_WSTATS == 3
+#if HF_WSTATS == 4
+// ... variant 4: histogram of the lanes that run a visit (c[11..13]) / a cell round (c[8..10]): at most 8, 9..24, more
+#define WHIST(base) do { const uint64_t e_ = __ballot(true); if ((int) (threadIdx.x & 63u) == __builtin_ctzll(e_)) { \
+        const int n_ = __builtin_popcountll(e_); wcnt_base()[(base) + (n_ <= 8 ? 0 : n_ <= 24 ? 1 : 2)]++; } } while (0)
+#define WSTATS_EXPORT(alive, best) do { if (alive) { const uint32_t *c = wcnt_base(); (best).hit = true; \
+        (best).t = (float) c[8] + 1024.f * (float) c[9] + 1048576.f * (float) c[10]; \
+        (best).u = (float) c[11] + 1024.f * (float) c[12] + 1048576.f * (float) c[13]; (best).v = 0.f; (best).prim = c[7]; } } while (0)
+#elif HF_WSTATS == 3
 // ... variant 3: c[8] = participants summed over the hand-offs of the batch, c[9] = those that took part in an earlier one
 #define WSTATS_EXPORT(alive, best) do { if (alive) { const uint32_t *c = wcnt_base(); (best).hit = true; \
         (best).t = (float) c[5] + 4096.f * (float) c[8]; (best).u = (float) c[6] + 4096.f * (float) c[9]; \
@@ -297,6 +311,9 @@ __device__ __forceinline__ void wstats_reset() { }
 #endif
 #ifndef HF_LINE_EPS
 #define HF_LINE_EPS 1e-6f // rounding of the sheared line, per cell of the grid's side (2e-6 until round 3)
+#endif
+#ifndef WHIST
+#define WHIST(base) do { } while (0)
 #endif
 // per-ray traversal constants (order space, cell units, re-based at t = tin)
 struct hf_trav {
@@ -365,20 +382,55 @@ __device__ __forceinline__ bool setup_ray(const hf_dev_field &f, float2 zr, v3 o
     const float zspan = fmaxf(zr.y - zr.x, fmaxf(__builtin_fabsf(zr.x), __builtin_fabsf(zr.y)));
     const float mz0 = 1e-5f * zspan + 1e-30f;
 
-    // clip against the inflated object-space bound (slab test, bbox.h:302-327)
-    float tin = 0.f, tout = maxt;
+    // The margins first: they depend on how far the ray travels to the grid (`reach`), measured with the entry into
+    // the bound inflated by the fixed amounts only (1e-4 in xy, mz0 in z) -- also for a ray that misses that bound.
+    const float oc[3] = { oo.x, oo.y, oo.z }, dc[3] = { od.x, od.y, od.z };
+    float rr[3];
+    float tin0 = 0.f;
     {
         const float lo[3] = { -1.f - 1e-4f, -1.f - 1e-4f, zr.x - mz0 };
         const float hi[3] = { 1.f + 1e-4f, 1.f + 1e-4f, zr.y + mz0 };
-        const float oc[3] = { oo.x, oo.y, oo.z }, dc[3] = { od.x, od.y, od.z };
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            rr[k] = 1.0f / dc[k];
+            if (dc[k] != 0.f) tin0 = fmaxf(tin0, fminf((lo[k] - oc[k]) * rr[k], (hi[k] - oc[k]) * rr[k]));
+        }
+        tin0 = tin0 - __builtin_fabsf(tin0) * 1e-6f;
+        tin0 = fmaxf(tin0, 0.f);
+    }
+    const float reach = __builtin_fabsf(oo.x) + __builtin_fabsf(oo.y) +
+                        tin0 * (__builtin_fabsf(od.x) + __builtin_fabsf(od.y)) + 2.f;
+    // xy margin: covers the rounding of the walk and the NOISE OF THE TRIANGLE TEST ITSELF -- how far beside the exact
+    // ray a triangle can lie and still be reported hit by the fp32 Moeller-Trumbore arithmetic -- which grows faster
+    // than linearly with the distance of the origin (against float64 geometry and the brute force over all cells:
+    // 0.001 cell from 3 units away, up to 1.7 cells from 50 units away on needle terrain at N = 4096).  Beyond a reach
+    // of 8 units the distance term therefore grows with (reach / 8)^2 (round 3: with the linear term and a cap of 0.3
+    // cell the walk missed ~1 such hit in 10^4 rays traced from 50 units away; the walk only gets slower with m);
+    // within 8 units -- every BASELINE configuration -- the distance term is what it was.  Capped at 8 cells so that the
+    // strip a ray walks (and the time of the launch) stays bounded however far its origin.  The constant part HF_M0 is
+    // pure slack on top of the distance term, which is never below 8 eps x (grid side) -- the rounding of the walk's own
+    // slab arithmetic; it was 1/64 cell until round 3 and fattened every sheared slab by 3x its curvature thickness on
+    // smooth terrain: at 1/256 a batch needs 4.7 instead of 5.7 cell rounds (forward -3 %, bounce rays -4 %).  Same
+    // formula in the oracle's walk; the band brute force (no margins at all) and the fuzz check that it suffices.
+    const float far = fmaxf(1.f, 0.125f * reach);
+    const float m = HF_M0 + fminf(8.f, 4.8e-7f * reach * fmaxf(hx, hy) * (far * far));
+
+    // clip against the object-space bound (slab test, bbox.h:302-327) inflated by what such a hit can reach: m cells in
+    // xy and m x (height span) in z on top of the fixed amounts -- every node test of the walk has that needle term,
+    // and without it here a ray traced from 40 units away lost a (noise) hit the brute force reports 1 % of the height
+    // span above the bound (round 3, the one mismatch of 4e9 fuzz rays against the band brute force)
+    float tin = 0.f, tout = maxt;
+    {
+        const float ex = 1e-4f + m / hx, ey = 1e-4f + m / hy, ez = __builtin_fmaf(m, zspan, mz0);
+        const float lo[3] = { -1.f - ex, -1.f - ey, zr.x - ez };
+        const float hi[3] = { 1.f + ex, 1.f + ey, zr.y + ez };
         bool outside = false;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             if (dc[k] == 0.f) {
                 outside |= (oc[k] < lo[k]) | (oc[k] > hi[k]);
             } else {
-                const float rr = 1.0f / dc[k];
-                const float t1 = (lo[k] - oc[k]) * rr, t2 = (hi[k] - oc[k]) * rr;
+                const float t1 = (lo[k] - oc[k]) * rr[k], t2 = (hi[k] - oc[k]) * rr[k];
                 tin = fmaxf(tin, fminf(t1, t2));
                 tout = fminf(tout, fmaxf(t1, t2));
             }
@@ -403,22 +455,6 @@ __device__ __forceinline__ bool setup_ray(const hf_dev_field &f, float2 zr, v3 o
     // |.|: a negative-zero component (d = -up, or a -0 surviving to_object) is mirrored by neither test above and
     // would give -inf here, which flips every slab test below; canonicalised it is the +inf of an axis-parallel ray
     r.idx = 1.0f / __builtin_fabsf(dx); r.idy = 1.0f / __builtin_fabsf(dy);
-    const float reach = __builtin_fabsf(oo.x) + __builtin_fabsf(oo.y) +
-                        tin * (__builtin_fabsf(od.x) + __builtin_fabsf(od.y)) + 2.f;
-    // xy margin: covers the rounding of the walk and the NOISE OF THE TRIANGLE TEST ITSELF -- how far beside the exact
-    // ray a triangle can lie and still be reported hit by the fp32 Moeller-Trumbore arithmetic -- which grows faster
-    // than linearly with the distance of the origin (against float64 geometry and the brute force over all cells:
-    // 0.001 cell from 3 units away, up to 1.7 cells from 50 units away on needle terrain at N = 4096).  Beyond a reach
-    // of 8 units the distance term therefore grows with (reach / 8)^2 (round 3: with the linear term and a cap of 0.3
-    // cell the walk missed ~1 such hit in 10^4 rays traced from 50 units away; the walk only gets slower with m);
-    // within 8 units -- every BASELINE configuration -- the distance term is what it was.  Capped at 8 cells so that the
-    // strip a ray walks (and the time of the launch) stays bounded however far its origin.  The constant part HF_M0 is
-    // pure slack on top of the distance term, which is never below 8 eps x (grid side) -- the rounding of the walk's own
-    // slab arithmetic; it was 1/64 cell until round 3 and fattened every sheared slab by 3x its curvature thickness on
-    // smooth terrain: at 1/256 a batch needs 4.7 instead of 5.7 cell rounds (forward -3 %, bounce rays -4 %).  Same
-    // formula in the oracle's walk; the band brute force (no margins at all) and 1.0e9 fuzz rays check that it suffices.
-    const float far = fmaxf(1.f, 0.125f * reach);
-    const float m = HF_M0 + fminf(8.f, 4.8e-7f * reach * fmaxf(hx, hy) * (far * far));
     r.mz = mz0 + 4.8e-7f * (__builtin_fabsf(oo.z) + tin * __builtin_fabsf(od.z) + zspan);
     r.gxm = gx + m; r.gxp = gx - m; r.gym = gy + m; r.gyp = gy - m;
     float thi = tout - tin;
@@ -530,7 +566,7 @@ __device__ __forceinline__ bool walk_round(const hf_dev_field &f, const Src &src
         // the mask may predate a hit: re-check the child's entry against the current t_hi
         const float te = fmaxf(((float) cx * S - r.gxm) * r.idx, ((float) cy * S - r.gym) * r.idy);
         if (te > thi) continue;
-        WCOUNT(5); WLANES(7, 0);
+        WCOUNT(5); WLANES(7, 0); WHIST(11);
         w.stk = (w.stk << 4) | (STK) w.cur;
         w.X = cx; w.Y = cy; --w.L;
         // the four children of (X,Y,L): sheared bounds on the fine levels, min/max boxes above
@@ -564,7 +600,7 @@ __device__ __forceinline__ bool walk_round(const hf_dev_field &f, const Src &src
     while (__ballot(w.pend != 0u) != 0ull) {
         WCOUNT(6);
         if (w.pend != 0u) {
-            WLANES(7, 16);
+            WLANES(7, 16); WHIST(8);
             const int j = __builtin_ctz(w.pend);
             w.pend &= w.pend - 1u;
             // (the lane's node (X,Y) is the level-1 node whose children the candidate cells are: actual cell = 2 * actual node + j)
@@ -709,7 +745,7 @@ __device__ __forceinline__ float wave_min16(const float (&h)[16], uint32_t lane,
 #define HF_BEAM_CAND (4 * HF_BEAM_ROWS)
 struct hf_beam_lds {
     struct { float4 box, pl, q01, q23; } e[HF_BEAM_CAND]; // (min z, max z) and record of the pass's nodes
-    float hdr[16];               // the beam (wave-uniform), parked here between passes instead of in registers
+    float hdr[20];               // the beam (wave-uniform), parked here between passes instead of in registers; [16] = largest xy margin
 };
 enum { BM_ISN, BM_ISX, BM_ICN, BM_ICX, BM_AS, BM_BS, BM_AC, BM_BC, BM_GCLO, BM_GCHI, BM_DCN, BM_DCX, BM_ZLO, BM_ZHI, BM_DZN, BM_DZX };
 // Returns false when it gives up -- an axis-parallel ray in the wave, or a beam wider than four nodes (rays that fan
@@ -754,6 +790,10 @@ __device__ __forceinline__ bool walk_beam(const hf_dev_field &f, const hf_ray_st
         // slabs the wave's rays can touch: [g - m, g + m + t_hi d] per lane, widened by the slack of this estimate
         const float sa = gsp - 1e-3f, sb = __builtin_fmaf(thi, dso, gsm);
         const float sb2 = sb + 1e-3f + 1e-6f * sb;
+        {   // largest xy margin of the wave's rays: the needle term of the beam's box test is m x (height range of the box)
+            const float mmax = wave_max_f32(alive ? rs.m : 0.f);
+            if (lane == 0u) lds->hdr[16] = mmax;
+        }
         smin = wave_min_u32(alive ? (uint32_t) fminf(fmaxf(sa * iS, 0.f), lim) : 0xFFFFFFFFu);
         smax = wave_max_u32(alive ? (uint32_t) fminf(fmaxf(sb2 * iS, 0.f), lim) : 0u);
     }
@@ -795,7 +835,7 @@ __device__ __forceinline__ bool walk_beam(const hf_dev_field &f, const hf_ray_st
                 float u0 = fmaxf(fmaxf(fS * isn - as, fC * icn - ac), 0.f), u1 = fminf(fminf((fS + S) * isx - bs, (fC + S) * icx - bc), T);
                 u0 = fmaxf(u0 - (1e-5f * u0 + 1e-5f), 0.f); u1 = u1 + (1e-5f * u1 + 1e-5f);
                 const float za = zlo + fminf(u0 * dzn, u1 * dzn), zb = zhi + fmaxf(u0 * dzx, u1 * dzx);
-                const float zs = 1e-5f * (__builtin_fabsf(za) + __builtin_fabsf(zb)) + 1e-30f;
+                const float zs = __builtin_fmaf(lds->hdr[16], box.y - box.x, 1e-5f * (__builtin_fabsf(za) + __builtin_fabsf(zb)) + 1e-30f);
                 cand = (u0 <= u1) & (za - zs <= box.y) & (zb + zs >= box.x);
                 if (cand) {
                     lds->e[lane].box = make_float4(box.x, box.y, 0.f, 0.f);
@@ -827,7 +867,8 @@ __device__ __forceinline__ bool walk_beam(const hf_dev_field &f, const hf_ray_st
                 const float ylo = (fYc - r.gym) * r.idy, yhi = (fYc + S - r.gyp) * r.idy;
                 const float u0 = fmaxf(fmaxf(xlo, ylo), 0.f), u1 = fminf(fminf(xhi, yhi), thi);
                 const float za = __builtin_fmaf(u0, r.dz, r.gz), zb = __builtin_fmaf(u1, r.dz, r.gz);
-                const bool mine = (u0 <= u1) & (fminf(za, zb) - r.mz <= cbox.y) & (fmaxf(za, zb) + r.mz >= cbox.x);
+                const float bz = __builtin_fmaf(rs.m, cbox.y - cbox.x, r.mz);
+                const bool mine = (u0 <= u1) & (fminf(za, zb) - bz <= cbox.y) & (fmaxf(za, zb) + bz >= cbox.x);
                 if (__ballot(mine) == 0ull) {
                     // nobody overlaps this node; done when nobody can reach its slab -- or any later one -- before its t_hi
                     const float tsk = ((float) sk * S - (xm ? r.gxm : r.gym)) * (xm ? r.idx : r.idy);

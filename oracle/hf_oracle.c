@@ -317,19 +317,49 @@ static void trace_hier(const hfo_field *f, const float o[3], const float d[3], f
     const int cw = f->W - 1, ch = f->H - 1, top = f->top;
     const float hx = 0.5f * (float) cw, hy = 0.5f * (float) ch;
 
-    /* clip against the (inflated) object-space bound, bbox.h:302-327 */
+    /* The margins first (round 3): `reach` is measured with the entry into the bound inflated by the fixed amounts
+     * only, also for a ray that misses that bound; then the bound itself (bbox.h:302-327) is inflated by what the
+     * triangle test's noise can reach -- m cells in xy, m x (height span) in z -- like every node test below.
+     * (Without it a ray traced from 40 units away lost a noise hit the brute force reports 1 % of the height span
+     * above the bound: the one mismatch of 4e9 fuzz rays against the band brute force.) */
     const float zspan = fmaxf(f->zmax - f->zmin, fmaxf(fabsf(f->zmin), fabsf(f->zmax)));
     const float mz0 = 1e-5f * zspan + 1e-30f;
-    float tin = 0.f, tout = maxt;
+    float rr[3];
+    float tin0 = 0.f;
     {
         const float lo[3] = { -1.f - 1e-4f, -1.f - 1e-4f, f->zmin - mz0 };
         const float hi[3] = {  1.f + 1e-4f,  1.f + 1e-4f, f->zmax + mz0 };
         for (int k = 0; k < 3; ++k) {
+            rr[k] = 1.0f / od[k];
+            if (od[k] != 0.f) tin0 = fmaxf(tin0, fminf((lo[k] - oo[k]) * rr[k], (hi[k] - oo[k]) * rr[k]));
+        }
+        tin0 = tin0 - fabsf(tin0) * 1e-6f;
+        if (tin0 < 0.f) tin0 = 0.f;
+    }
+    /* The xy margin has to cover the noise of
+     * the fp32 triangle test itself -- how far beside the exact ray a triangle can lie and still be reported hit --
+     * which grows faster than linearly with the distance of the origin (measured against float64 geometry and the
+     * brute force over ALL cells: 0.001 cell from 3 units away, 0.02 .. 1.7 cells from 50 units away on needle terrain
+     * at N = 285 .. 4096).  Round 3 (a fuzz mismatch of the linear term, tests/test_oracle_band.py::
+     * test_far_origin_needle_regression): beyond a reach of 8 units the distance term grows with the square of
+     * reach / 8 (the walk only gets slower); within 8 units -- every BASELINE configuration -- it is what it was.
+     * The constant part is slack on top (1/64 cell until round 3, 1/256 since: the distance term alone is never
+     * below 8 eps x the grid's side, the rounding of the slab arithmetic). */
+    const float reach = fabsf(oo[0]) + fabsf(oo[1]) + tin0 * (fabsf(od[0]) + fabsf(od[1])) + 2.f;
+    const float far = fmaxf(1.f, 0.125f * reach);
+    /* capped at 8 cells: the strip the walk visits stays bounded however far the origin (a ray from 200 units away
+     * at N = 4096 would otherwise ask for 120 cells each side) */
+    const float m = 0.00390625f + fminf(8.f, 4.8e-7f * reach * fmaxf(hx, hy) * (far * far));
+    float tin = 0.f, tout = maxt;
+    {
+        const float ex = 1e-4f + m / hx, ey = 1e-4f + m / hy, ez = fmaf(m, zspan, mz0);
+        const float lo[3] = { -1.f - ex, -1.f - ey, f->zmin - ez };
+        const float hi[3] = {  1.f + ex,  1.f + ey, f->zmax + ez };
+        for (int k = 0; k < 3; ++k) {
             if (od[k] == 0.f) {
                 if (oo[k] < lo[k] || oo[k] > hi[k]) return;
             } else {
-                float r = 1.0f / od[k];
-                float t1 = (lo[k] - oo[k]) * r, t2 = (hi[k] - oo[k]) * r;
+                float t1 = (lo[k] - oo[k]) * rr[k], t2 = (hi[k] - oo[k]) * rr[k];
                 tin = fmaxf(tin, fminf(t1, t2));
                 tout = fminf(tout, fmaxf(t1, t2));
             }
@@ -350,20 +380,6 @@ static void trace_hier(const hfo_field *f, const float o[3], const float d[3], f
     if (fy) { gy = Wp - gy; dy = -dy; }
     /* |.|: a negative-zero component is not mirrored above and would give -inf; +inf for axis-parallel rays */
     const float idx = 1.0f / fabsf(dx), idy = 1.0f / fabsf(dy);
-    /* margins scale with the distance the ray travelled to reach the grid.  The xy margin has to cover the noise of
-     * the fp32 triangle test itself -- how far beside the exact ray a triangle can lie and still be reported hit --
-     * which grows faster than linearly with the distance of the origin (measured against float64 geometry and the
-     * brute force over ALL cells: 0.001 cell from 3 units away, 0.02 .. 1.7 cells from 50 units away on needle terrain
-     * at N = 285 .. 4096).  Round 3 (a fuzz mismatch of the linear term, tests/test_oracle_band.py::
-     * test_far_origin_needle_regression): beyond a reach of 8 units the distance term grows with the square of
-     * reach / 8 (the walk only gets slower); within 8 units -- every BASELINE configuration -- it is what it was.
-     * The constant part is slack on top (1/64 cell until round 3, 1/256 since: the distance term alone is never
-     * below 8 eps x the grid's side, the rounding of the slab arithmetic). */
-    const float reach = fabsf(oo[0]) + fabsf(oo[1]) + tin * (fabsf(od[0]) + fabsf(od[1])) + 2.f;
-    const float far = fmaxf(1.f, 0.125f * reach);
-    /* capped at 8 cells: the strip the walk visits stays bounded however far the origin (a ray from 200 units away
-     * at N = 4096 would otherwise ask for 120 cells each side) */
-    const float m = 0.00390625f + fminf(8.f, 4.8e-7f * reach * fmaxf(hx, hy) * (far * far));
     const float mz = mz0 + 4.8e-7f * (fabsf(oo[2]) + tin * fabsf(od[2]) + zspan);
     float thi = (tout - tin);
     thi = thi + thi * 1e-6f + 1e-30f;
@@ -403,7 +419,7 @@ static void trace_hier(const hfo_field *f, const float o[3], const float d[3], f
                 float z0 = fmaf(t0, dz, gz), z1 = fmaf(t1, dz, gz);
                 /* the triangle test may report a hit up to m cells beside the walk's ray; on a needle
                  * triangle that is up to m x (height range of the cell) above or below it */
-                const float mzz = fmaf(m, zhi - zlo, mz);
+                const float mzz = fmaf(m + 1e-6f * (float) (1 << top), zhi - zlo, mz); /* (+ the slack the HIP walk's sheared line carries) */
                 float rlo = fminf(z0, z1) - mzz, rhi = fmaxf(z0, z1) + mzz;
                 overlap = rlo <= zhi && rhi >= zlo;
             }

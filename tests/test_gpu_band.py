@@ -127,3 +127,24 @@ def test_far_origin_needle_regression_on_the_gpu(hf, oracle):
     t, u, v, prim = fn.ray_intersect_preliminary(rays, naive=True, nthreads=16)
     assert np.array_equal(prim, pi.prim_index.cpu().numpy().view(np.uint32))
     assert np.array_equal(t.view(np.uint32), pi.t.cpu().numpy().view(np.uint32))
+
+
+def test_noise_hit_above_the_bound_regression_on_the_gpu(hf, oracle):
+    """the second round-3 fuzz find (tests/test_oracle_band.py::test_noise_hit_above_the_bound_regression) through the HIP
+    kernels: closest hit, any hit and the fused record of the single ray (a wave of copies and a lone ray)"""
+    from test_oracle_band import _fuzz_scene
+    h, mh, tw = _fuzz_scene(301, 166)
+    f = oracle.OracleField(h, max_height=mh, to_world=tw)
+    shape = hf.Heightfield(heightfield=torch.from_numpy(h), max_height=mh, to_world=torch.from_numpy(tw))
+    r = np.array([[24.74660873413086, -6.202888011932373, 2.355172634124756,
+                   -0.8037796020507812, 0.23658400774002075, -0.07390778511762619, np.inf]], np.float32).T
+    t, u, v, prim = f.ray_intersect_preliminary(r, band=True, nthreads=16)
+    assert int(prim[0]) == 6444120
+    for copies in (64, 1):
+        rt = torch.from_numpy(np.repeat(r, copies, 1)).cuda()
+        ray = hf.Ray3f(rt[0:3].contiguous(), rt[3:6].contiguous(), rt[6].contiguous())
+        pi = shape.ray_intersect_preliminary(ray)
+        assert np.all(pi.prim_index.cpu().numpy().view(np.uint32) == 6444120) and np.all(pi.t.cpu().numpy() == t[0])
+        assert bool(shape.ray_test(ray).all())
+        si = shape.ray_intersect(ray)
+        assert np.all(si.t.cpu().numpy() == t[0]) and np.all(si.prim_index.cpu().numpy().view(np.uint32) == 6444120)

@@ -125,6 +125,24 @@ def test_far_origin_needle_regression():
     _same(f.ray_intersect_preliminary(r, band=True, nthreads=NT), naive)
 
 
+def test_noise_hit_above_the_bound_regression():
+    """Second round-3 fuzz find (FUZZ_BAND=1 FUZZ_MAXDIM=3000, seed 301, scene 166: 2341 x 2562 white-noise heights, affine
+    to_world, object-space origin 42 units from the grid): the fp32 triangle test reports a hit at a point where the
+    exact ray is still 1 % of the height span ABOVE the bound (exact barycentrics (0.014, 1.118): outside the needle by
+    0.13 cell, 0.16 of fp32 noise in v).  The walks clipped the ray to the bound inflated by 1e-5 of the span and never
+    looked there; the band and the full brute force report it.  The clip is now inflated by the same needle term as
+    every node test: m cells in xy, m x span in z."""
+    h, mh, tw = _fuzz_scene(301, 166)
+    assert h.shape == (2562, 2341) and tw is not None
+    f = O.OracleField(h, max_height=mh, to_world=tw)
+    r = np.array([[24.74660873413086, -6.202888011932373, 2.355172634124756,
+                   -0.8037796020507812, 0.23658400774002075, -0.07390778511762619, np.inf]], np.float32).T
+    naive = f.ray_intersect_preliminary(r, naive=True, nthreads=NT)
+    assert int(naive[3][0]) == 6444120
+    _same(f.ray_intersect_preliminary(r, nthreads=NT), naive)
+    _same(f.ray_intersect_preliminary(r, band=True, nthreads=NT), naive)
+
+
 def test_far_origins_on_needles_against_the_full_brute_force():
     """rays traced from 50 units away onto white-noise heights (129^2, every cell a needle): hierarchical walk == brute
     force over ALL cells == band.  (At N = 4096 the same regime leaves ~5 rays in 10^6 where a grazing hit's fp32
