@@ -210,11 +210,11 @@ int hf_dims(const hf_field_t *hf, uint32_t *width, uint32_t *height);
  *
  * Results: the closest hit is the minimum of (t, -prim_index) over the triangles the reference's fp32
  * Moeller-Trumbore arithmetic (include/mitsuba/render/mesh.h:357-380) reports as hit -- what a brute force over
- * every triangle returns, bit for bit, for ray origins within 8 object-space units of the field on any terrain and at
- * any distance on terrain whose cells are not needles.  That test is itself ill-conditioned for far origins on needle
- * terrain (cells ~1000x taller than wide): from 50 / 200 units away, 6e-5 / 9e-4 of such rays differ from the brute
- * force by a triangle of fp32 noise one cell beside the ray (DESIGN.md 4.1 "far origins",
- * profiles/r03_far_origin.txt), as a BVH over the same triangles would. */
+ * every triangle returns, bit for bit.  That test is itself ill-conditioned for distant origins on needle terrain
+ * (cells hundreds of times taller than wide: the computed barycentrics are off by half a cell from 8 object units
+ * away at 4096^2, by more than a cell from 50): a few rays in 10^5 then carry a hit of fp32 noise, which this library
+ * reports whenever the noise stays within its margins -- in every such case resolved against the full brute force so
+ * far (profiles/r03_far_origin.txt) -- and which a BVH over the same triangles may or may not report. */
 
 /* Replaces: Shape::ray_intersect_preliminary(const Ray3f&, Mask)
  * (include/mitsuba/render/shape.h:137-138, wrapper shape.h:621-629; called from

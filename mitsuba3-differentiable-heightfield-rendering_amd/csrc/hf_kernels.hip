@@ -406,7 +406,7 @@ __device__ __forceinline__ bool setup_ray(const hf_dev_field &f, float2 zr, v3 o
     // 0.001 cell from 3 units away, up to 1.7 cells from 50 units away on needle terrain at N = 4096).  Beyond a reach
     // of 8 units the distance term therefore grows with (reach / 8)^2 (round 3: with the linear term and a cap of 0.3
     // cell the walk missed ~1 such hit in 10^4 rays traced from 50 units away; the walk only gets slower with m);
-    // within 8 units -- every BASELINE configuration -- the distance term is what it was.  Capped at 8 cells so that the
+    // up to a reach of 8 units -- most rays of the BASELINE configurations; a few reach 9.5 -- the distance term is what it was.  Capped at 8 cells so that the
     // strip a ray walks (and the time of the launch) stays bounded however far its origin.  The constant part HF_M0 is
     // pure slack on top of the distance term, which is never below 8 eps x (grid side) -- the rounding of the walk's own
     // slab arithmetic; it was 1/64 cell until round 3 and fattened every sheared slab by 3x its curvature thickness on
