@@ -276,7 +276,12 @@ __device__ __forceinline__ uint32_t *wcnt_base() {
 #define WLANES(k, sh) do { const uint64_t e_ = __ballot(true); if ((int) (threadIdx.x & 63u) == __builtin_ctzll(e_)) wcnt_base()[k] += (uint32_t) __builtin_popcountll(e_) << (sh); } while (0)
 __device__ __forceinline__ void wstats_reset() { if ((threadIdx.x & 63u) < 16u) wcnt_base()[threadIdx.x & 63u] = 0u; }
 // diagnostic build (scripts/wstats.py): the counters of this batch replace the hit record
-#if HF_WSTATS == 4
+#if HF_WSTATS == 5
+// ... variant 5: at the points between two converged rounds where at most 8 lanes still walk: c[10] such points,
+// c[8] walkers, c[9] / c[11] pending level-1 / level-2 siblings they hold (work idle lanes could take)
+#define WSTATS_EXPORT(alive, best) do { if (alive) { const uint32_t *c = wcnt_base(); (best).hit = true; \
+        (best).t = (float) c[10] + 4096.f * (float) c[8]; (best).u = (float) c[9] + 4096.f * (float) c[11]; (best).v = 0.f; (best).prim = c[7]; } } while (0)
+#elif HF_WSTATS == 4
 // ... variant 4: histogram of the lanes that run a visit (c[11..13]) / a cell round (c[8..10]): at most 8, 9..24, more
 #define WHIST(base) do { const uint64_t e_ = __ballot(true); if ((int) (threadIdx.x & 63u) == __builtin_ctzll(e_)) { \
         const int n_ = __builtin_popcountll(e_); wcnt_base()[(base) + (n_ <= 8 ? 0 : n_ <= 24 ? 1 : 2)]++; } } while (0)
@@ -644,6 +649,20 @@ __device__ __forceinline__ bool walk_subtree_from(const hf_dev_field &f, const S
     bool hit_any = false;
     do {
         hit_any |= walk_round<ANY>(f, src, rs, r, fx, fy, fxm, fym, thi, best, w);
+#if defined(HF_WSTATS) && HF_WSTATS == 5
+        {   // between two rounds with at most 8 lanes still walking: how many level-1 siblings (pending children of the
+            // lane's level-2 ancestor) and level-2 siblings could be handed to idle lanes
+            const uint64_t wm = __ballot(!w.fin);
+            const int nw = __builtin_popcountll(wm);
+            if (nw != 0 && nw <= 8 && !w.fin) {
+                const uint32_t b1 = w.L == 1 ? (uint32_t) __builtin_popcount(w.stk & 15u) : 0u;
+                const uint32_t b2 = w.L == 1 ? (uint32_t) __builtin_popcount((w.stk >> 4) & 15u) : 0u;
+                uint32_t *c = wcnt_base();
+                atomicAdd(&c[9], b1); atomicAdd(&c[11], b2); atomicAdd(&c[8], 1u);
+                if ((threadIdx.x & 63u) == (uint32_t) __builtin_ctzll(wm)) c[10]++;
+            }
+        }
+#endif
     } while (__ballot(!w.fin) != 0ull);
     return hit_any;
 }
