@@ -1027,7 +1027,9 @@ struct hf_si_dev {
 __device__ __forceinline__ void st(float *p, size_t ub, uint32_t lo, float v) { if (p) __builtin_nontemporal_store(v, &(p + ub)[lo]); }
 #define st3(p, ub, lo, v) do { st((p)[0], ub, lo, (v).x); st((p)[1], ub, lo, (v).y); st((p)[2], ub, lo, (v).z); } while (0)
 
+#ifndef HF_GRAB
 #define HF_GRAB 256 // most rays a wave takes from the work counter per fetch (hf_grab_for); 512 before the per-XCD counters
+#endif
 // Scratch block of one trace launch (zeroed by hf_launch_trace): the per-XCD work counters.
 #define HF_SCR_BYTES 1024
 #ifndef HF_COH_WINDOW
