@@ -1323,12 +1323,18 @@ static hf_si_dev to_dev(const hf_si_t *s) {
     return d;
 }
 
-// Rays per fetch: 512 for big wavefronts (a single counter serves ~80 fetches/us, which caps the rate of
-// rays that only stream), fewer for small ones so that every resident wave gets several fetches --
-// a fetch of 512 traversing rays is ~0.4 ms of work, the whole launch for a 4 M-ray wavefront.
+// Rays per fetch: HF_GRAB for big wavefronts (a single counter serves ~80 fetches/us, which caps the rate of rays
+// that only stream), fewer for smaller ones so that every resident wave gets about HF_FETCHES_PER_WAVE fetches: the
+// launch ends when its slowest wave does, and a fetch of 256 incoherent rays is 50 us of work.  Measured with 4 / 12 /
+// 24 / 48 fetches per wave (profiles/r03_ab/r03_fpw): a 4.19 M-ray wavefront (configs[2]) 0.435 / 0.393 / 0.394 /
+// 0.393 ms fused, the bench's 16.5 M bounce rays 3.25 / 3.26 / 3.17 / 3.16 ms; the 67.1 M-ray wavefront takes HF_GRAB
+// either way.
 static uint32_t hf_grab_for(size_t n) {
     const size_t resident = 256 * 4 * HF_TRACE_WAVES; // waves the launch keeps on the chip (about)
-    size_t g = (n / (resident * 4) + 63) / 64 * 64; // ~4 fetches per wave
+#ifndef HF_FETCHES_PER_WAVE
+#define HF_FETCHES_PER_WAVE 24
+#endif
+    size_t g = (n / (resident * HF_FETCHES_PER_WAVE) + 32) / 64 * 64; // about that many fetches per wave (rounded to whole batches)
     if (g < 64) g = 64;
     if (g > HF_GRAB) g = HF_GRAB;
     return (uint32_t) g;
