@@ -1329,14 +1329,20 @@ static hf_si_dev to_dev(const hf_si_t *s) {
 // 24 / 48 fetches per wave (profiles/r03_ab/r03_fpw): a 4.19 M-ray wavefront (configs[2]) 0.435 / 0.393 / 0.394 /
 // 0.393 ms fused, the bench's 16.5 M bounce rays 3.25 / 3.26 / 3.17 / 3.16 ms; the 67.1 M-ray wavefront takes HF_GRAB
 // either way.
-static uint32_t hf_grab_for(size_t n) {
+#ifndef HF_GRAB01
+#define HF_GRAB01 512 // cap of the closest-hit / any-hit launches, which store 16 / 1 bytes per ray: 67.1 M rays in fetches of
+                      // 512 instead of 256: closest hit 2.13 -> 2.10 ms, any hit 1.94 -> 1.88 ms (profiles/r03_ab/r03_g01); the fused
+                      // launch loses 1 % with 512
+#endif
+static uint32_t hf_grab_for(size_t n, int mode) {
     const size_t resident = 256 * 4 * HF_TRACE_WAVES; // waves the launch keeps on the chip (about)
 #ifndef HF_FETCHES_PER_WAVE
 #define HF_FETCHES_PER_WAVE 24
 #endif
     size_t g = (n / (resident * HF_FETCHES_PER_WAVE) + 32) / 64 * 64; // about that many fetches per wave (rounded to whole batches)
     if (g < 64) g = 64;
-    if (g > HF_GRAB) g = HF_GRAB;
+    const size_t cap = mode == 2 ? (size_t) HF_GRAB : (size_t) HF_GRAB01;
+    if (g > cap) g = cap;
     return (uint32_t) g;
 }
 
@@ -1356,7 +1362,7 @@ void hf_launch_trace(int mode, const hf_dev_field &f, size_t n, const hf_rays_t 
     memset(&sd, 0, sizeof(sd));
     if (si) sd = to_dev(si);
     const hf_rays_dev r = to_dev(rays);
-    const uint32_t grab = hf_grab_for(n);
+    const uint32_t grab = hf_grab_for(n, mode);
     size_t waves = (n + grab - 1) / grab, blocks = (waves + 3) / 4;
     const size_t per_cu = mode == 2 ? HF_TRACE_WAVES_FUSED : HF_TRACE_WAVES;
     if (blocks > 256 * per_cu) blocks = 256 * per_cu; // the resident set: that many workgroups per CU
