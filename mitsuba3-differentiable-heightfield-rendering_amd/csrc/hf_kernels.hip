@@ -1297,14 +1297,22 @@ __global__ __launch_bounds__(HF_BLOCK, (MODE == 2 ? HF_TRACE_WAVES_FUSED : HF_TR
     }
 }
 
+#ifndef HF_FLAT_GRID_CAP
 #define HF_FLAT_GRID_CAP (256 * 64)
-static int grid_for(size_t n) {
+#endif
+static int grid_for(size_t n, size_t cap = HF_FLAT_GRID_CAP) {
     size_t blocks = (n + HF_BLOCK - 1) / HF_BLOCK;
-    const size_t cap = HF_FLAT_GRID_CAP; // grid-stride kernels: many short blocks balance better than one resident set
+    // grid-stride kernels: many short blocks balance better than one resident set
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     return (int) blocks;
 }
+// hf_si_kernel streams 148 bytes per ray and keeps nothing per block: one block per 256 rays (no grid stride up to
+// 67 M rays) instead of 16384 blocks: 1.44 -> 1.24 ms on the bench wavefront (profiles/r03_ab/r03_sicap).  The adjoint
+// (an LDS tile to clear per wave) is best at the default cap (r03_cap).
+#ifndef HF_SI_GRID_CAP
+#define HF_SI_GRID_CAP (256 * 1024)
+#endif
 
 static hf_rays_dev to_dev(const hf_rays_t *r) {
     hf_rays_dev d;
@@ -1467,7 +1475,7 @@ void hf_launch_si(const hf_dev_field &f, size_t n, const hf_rays_t *rays, const 
     a.f = f; a.n = n; a.rays = to_dev(rays);
     a.pi.t = pi->t; a.pi.u = pi->prim_uv[0]; a.pi.v = pi->prim_uv[1]; a.pi.prim = pi->prim_index;
     a.active = active; a.sio = to_dev(si); a.flags = flags;
-    hipLaunchKernelGGL(hf_si_kernel, dim3(grid_for(n)), dim3(HF_BLOCK), 0, stream, a);
+    hipLaunchKernelGGL(hf_si_kernel, dim3(grid_for(n, HF_SI_GRID_CAP)), dim3(HF_BLOCK), 0, stream, a);
 }
 
 // ---------------------------------------------------------------------------------
