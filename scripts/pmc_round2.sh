@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage (on the GPU box, via gpurun): scripts/pmc_round2.sh TAG [kinds...]
 # SQ issue/stall counters of the trace kernel on the bench wavefront, reduced to CSV.
-set -e
+set -euo pipefail
 TAG=${1:-pmc}; shift || true
 KINDS=${@:-fwd miss}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}

@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage (GPU box): scripts/prof_adj.sh TAG : SQ / TCP counters of hf_adjoint_kernel on the bench workload (separate --pmc passes)
-set -e
+set -euo pipefail
 TAG=${1:-adj}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/$TAG

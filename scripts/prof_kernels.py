@@ -16,23 +16,40 @@ ap.add_argument("--grid", type=int, default=4096)
 ap.add_argument("--film", type=int, default=1024)
 ap.add_argument("--spp", type=int, default=64)
 ap.add_argument("--iters", type=int, default=5)
+ap.add_argument("--pad", type=int, default=0, help="floats of padding between the SoA rows of every buffer (row pitch = R + pad; 0 = contiguous rows, 2^28 B apart on the bench wavefront)")
 ap.add_argument("kinds", nargs="*", default=["fwd", "prelim", "si", "adj", "test", "miss", "mips", "sec_fwd", "sec_test"])
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 N, R = a.grid, a.film * a.film * a.spp
 lib = _capi.lib()
 shape = hf_amd.Heightfield(heightfield=hf_amd.workload.sine_heights(N, N, device=dev), max_height=0.5)
-rays = hf_amd.workload.ortho_rays(a.film, a.film, a.spp, dev)
-t = torch.empty(R, device=dev); uv = torch.empty((2, R), device=dev); prim = torch.empty(R, dtype=torch.int32, device=dev)
-si = torch.empty((18, R), device=dev); gsi = torch.zeros((18, R), device=dev)
+rays_c = hf_amd.workload.ortho_rays(a.film, a.film, a.spp, dev)
+P = R + a.pad   # row pitch in elements: every [k, R] buffer below is the first R columns of a [k, P] allocation
+def rowbuf(k, zero=False):
+    b = (torch.zeros if zero else torch.empty)((k, P), device=dev)
+    return b[:, :R]
+def rowptrs(v):   # device addresses of the rows of such a view
+    return [v.data_ptr() + 4 * P * k for k in range(v.shape[0])]
+def rays_struct(v):
+    p = rowptrs(v); r = _capi.hf_rays_t()
+    for k in range(3): r.o[k] = p[k]; r.d[k] = p[3 + k]
+    r.maxt = p[6]
+    return r
+rays = rowbuf(7); rays.copy_(rays_c)
+if a.pad == 0: rays = rays_c
+else: del rays_c
+pib = rowbuf(4)  # pi: t, u, v, prim_index (as bits) -- four rows of one allocation (separate [R] tensors at pad 0: the same 2^28 B pitch)
+t, uv, prim = pib[0], pib[1:3], pib[3].view(torch.int32)
+si = rowbuf(18); gsi = rowbuf(18, zero=True)
 hit8 = torch.empty(R, dtype=torch.uint8, device=dev)
 grad_h = torch.zeros((N, N), device=dev)
 st = torch.cuda.current_stream(dev).cuda_stream
-r_s = shape._rays_struct(rays[0:3], rays[3:6], rays[6]); pi_s = shape._pi_struct(t, uv, prim)
-si_s = _fill(_capi.hf_si_t(), _DIFF_ROWS, _rows(si, R)); g_s = _fill(_capi.hf_si_grad_t(), _DIFF_ROWS, _rows(gsi, R))
+r_s = rays_struct(rays)
+pi_s = _capi.hf_pi_t(); pp = rowptrs(pib); pi_s.t = pp[0]; pi_s.prim_uv[0] = pp[1]; pi_s.prim_uv[1] = pp[2]; pi_s.prim_index = pp[3]
+si_s = _fill(_capi.hf_si_t(), _DIFF_ROWS, rowptrs(si)); g_s = _fill(_capi.hf_si_grad_t(), _DIFF_ROWS, rowptrs(gsi))
 flags = int(hf_amd.RayFlags.All)
-miss = rays.clone(); miss[5] = 1.0; miss[3] = 0; miss[4] = 0; miss[2] = 5.0   # pointing up, above the box
-m_s = shape._rays_struct(miss[0:3], miss[3:6], miss[6])
+miss = rowbuf(7); miss.copy_(rays); miss[5] = 1.0; miss[3] = 0; miss[4] = 0; miss[2] = 5.0   # pointing up, above the box
+m_s = rays_struct(miss)
 fn = {
     "fwd": lambda: _capi.check(lib.hf_ray_intersect(shape._h, R, C.byref(r_s), flags, None, C.byref(pi_s), C.byref(si_s), st)),
     "prelim": lambda: _capi.check(lib.hf_ray_intersect_preliminary(shape._h, R, C.byref(r_s), None, C.byref(pi_s), st)),

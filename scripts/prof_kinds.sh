@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage (GPU box): scripts/prof_kinds.sh TAG : rocprofv3 kernel stats of single launches of every hot-path entry on the bench workload
-set -e
+set -euo pipefail
 TAG=${1:-kinds}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/$TAG

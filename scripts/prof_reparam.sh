@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage (GPU box): scripts/prof_reparam.sh TAG : rocprofv3 kernel stats of the reparameterisation backward (4 auxiliary rays, 67.1 M rays)
-set -e
+set -euo pipefail
 TAG=${1:-reparam}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/$TAG

@@ -2,7 +2,7 @@
 # usage (on the GPU box, via gpurun): scripts/profile_round.sh TAG [SOURCE]   (SOURCE: commit the profile is taken at)
 # rocprofv3 kernel stats of the bench command + PMC traffic / instruction counters of the kernels, reduced to
 # small CSV files under gpurun_out/TAG/ (the rocpd databases are deleted: gpurun copies back at most 64 MiB).
-set -e
+set -euo pipefail
 TAG=${1:-prof}
 SRC=${2:-unknown}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
