@@ -102,6 +102,19 @@ if "reparam" in a.kinds:
         dd, det = hf_amd.reparameterize_ray(shape, ray_o, num_rays=4, kappa=1e5, exponent=3.0)
         ((dd * gdir).sum() + (det * gdv).sum()).backward()
     fn["reparam"] = _reparam
+def clocks():
+    """current sclk / mclk of the first card as sysfs reports them (read right after the timed launches; informative only)"""
+    if not os.environ.get("HF_PROF_CLOCKS"): return ""
+    import glob
+    out = []
+    for nm in ("pp_dpm_sclk", "pp_dpm_mclk"):
+        try:
+            f = sorted(glob.glob(f"/sys/class/drm/card*/device/{nm}"))[0]
+            cur = [l.split()[1] for l in open(f) if l.strip().endswith("*")]
+            out.append(f"{nm[7:]} {cur[0] if cur else '?'}")
+        except Exception as e:
+            out.append(f"{nm[7:]} n/a")
+    return "  [" + ", ".join(out) + "]"
 for k in a.kinds:
     fn[k](); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -110,4 +123,4 @@ for k in a.kinds:
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / a.iters
     nr = nrays.get(k, R)
-    print(f"{k:8s} {ms:9.3f} ms  {nr / ms / 1e3:10.1f} Mrays/s  ({nr} rays)", flush=True)
+    print(f"{k:8s} {ms:9.3f} ms  {nr / ms / 1e3:10.1f} Mrays/s  ({nr} rays){clocks()}", flush=True)
