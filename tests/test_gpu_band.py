@@ -148,3 +148,23 @@ def test_noise_hit_above_the_bound_regression_on_the_gpu(hf, oracle):
         assert bool(shape.ray_test(ray).all())
         si = shape.ray_intersect(ray)
         assert np.all(si.t.cpu().numpy() == t[0]) and np.all(si.prim_index.cpu().numpy().view(np.uint32) == 6444120)
+
+
+def test_walk_needle_term_regression_on_the_gpu(hf, oracle):
+    """the six rays of tests/test_oracle_band.py::test_walk_needle_term_regression (white noise, N = 4096, origins 8
+    units away: the rays on which the oracle's walk -- before its round-4 needle term -- or the band brute force lose
+    to the brute force over all 16.7 M cells) through the HIP kernels: closest hit == the full brute force's, as a
+    wave of copies and as lone rays in one launch"""
+    from test_oracle_band import _far_origin_sweep_case
+    h, mh, r_all = _far_origin_sweep_case(4)
+    idx = np.array([95386, 138178, 279488, 286422, 288405, 379107])
+    r = np.ascontiguousarray(r_all[:, idx])
+    f = oracle.OracleField(h, max_height=mh)
+    t, u, v, prim = f.ray_intersect_preliminary(r, naive=True, nthreads=16)
+    assert prim.tolist() == [18618549, 5812674, 20465175, 14063183, 11430767, 13598460]
+    shape = hf.Heightfield(heightfield=torch.from_numpy(h), max_height=mh)
+    for copies in (64, 1):
+        rt = torch.from_numpy(np.repeat(r, copies, 1)).cuda()
+        pi = shape.ray_intersect_preliminary(hf.Ray3f(rt[0:3].contiguous(), rt[3:6].contiguous(), rt[6].contiguous()))
+        assert np.array_equal(pi.prim_index.cpu().numpy().view(np.uint32), np.repeat(prim, copies))
+        assert np.array_equal(pi.t.cpu().numpy().view(np.uint32), np.repeat(t.view(np.uint32), copies))

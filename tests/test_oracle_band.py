@@ -158,3 +158,46 @@ def test_far_origins_on_needles_against_the_full_brute_force():
     naive = f.ray_intersect_preliminary(r, naive=True, nthreads=NT)
     _same(f.ray_intersect_preliminary(r, nthreads=NT), naive)
     _same(f.ray_intersect_preliminary(r, band=True, nthreads=NT), naive)
+
+
+def _far_origin_sweep_case(case):
+    """heights and rays of case `case` of tests/tools/far_origin_sweep.py (the tool draws everything from ONE generator,
+    case after case: replay the draws of the cases before it)"""
+    cases = [(1024, 8, 1.0), (1024, 50, 1.0), (2048, 50, 0.2), (4096, 3, 0.5), (4096, 8, 0.5), (4096, 50, 0.5), (4096, 200, 0.5)]
+    rng = np.random.default_rng(1)
+    n = 400000
+    for N, dist, mh in cases[:case + 1]:
+        h = rng.uniform(0, 1, (N, N)).astype(np.float32)
+        c = rng.uniform(-1, 1, (2, n)); dirs = rng.normal(size=(3, n))
+        dirs[2] = -np.abs(dirs[2]) * rng.uniform(0.05, 1.0, n); dirs /= np.linalg.norm(dirs, axis=0)
+    o = np.concatenate([c, np.full((1, n), mh * 0.5)]) - dirs * dist
+    return h, mh, np.concatenate([o, dirs, np.full((1, n), np.inf)]).astype(np.float32)
+
+
+def test_walk_needle_term_regression():
+    """Round 3 recorded a KNOWN defect of the oracle's hierarchical walk (profiles/r03_far_origin.txt, N = 4096, origins
+    8 units away, white noise: `walk==full 3 of 5`): its needle term  m x (height range of the node)  fell short of a
+    noise hit the full brute force reports and the HIP walk's records ((|a| + |b| + r) m) cover.  Round 4: the term is
+    2 m x (range) -- each partial derivative of a triangle is bounded by the range of its cell.  The six rays of that
+    sweep case on which the (old or new) walk and the band brute force disagree, against the brute force over ALL
+    16.7 M cells: rays 3 (index 286422 of the sweep: the old walk returned prim 13694748) and 2, 5 (the old walk
+    agreed with the band, both wrong) are the regression vectors; on the other three only the band is wrong (its
+    +-2 cells are too narrow for this noise)."""
+    h, mh, r_all = _far_origin_sweep_case(4)
+    idx = np.array([95386, 138178, 279488, 286422, 288405, 379107])
+    bits = np.array([[3230957312, 1085054455, 1077890069, 1058518162, 3208292116, 3199159317, 2139095040],
+                     [1082935739, 3232252917, 1069104658, 3206823863, 1061197526, 3189325330, 2139095040],
+                     [3230772522, 1081198249, 1083502862, 1060101661, 3203585381, 3205296398, 2139095040],
+                     [3233414553, 1081089437, 1083176727, 1059808475, 3204772134, 3204970263, 2139095040],
+                     [3231223158, 1081597035, 1081004274, 1060303672, 3205579551, 3202273522, 2139095040],
+                     [1086063190, 3225221146, 1079471574, 3210145926, 1052891243, 3200740822, 2139095040]], np.uint32)
+    r = np.ascontiguousarray(bits.view(np.float32).T)
+    assert np.array_equal(r.view(np.uint32), np.ascontiguousarray(r_all[:, idx]).view(np.uint32)), "the sweep's draws changed"
+    f = O.OracleField(h, max_height=mh)
+    naive = f.ray_intersect_preliminary(r, naive=True, nthreads=NT)
+    assert naive[3].tolist() == [18618549, 5812674, 20465175, 14063183, 11430767, 13598460]
+    assert naive[0].view(np.uint32).tolist() == [1088939504, 1086577901, 1089473464, 1089545076, 1089231128, 1089048274]
+    _same(f.ray_intersect_preliminary(r, nthreads=NT), naive)
+    # the band brute force has the old walk's ray, and loses the five others to noise wider than its two cells
+    band = f.ray_intersect_preliminary(r, band=True, nthreads=NT)
+    assert int(band[3][3]) == 14063183 and int((band[3] != naive[3]).sum()) == 5

@@ -7,7 +7,7 @@ noise (setup_ray, hf_kernels.hip); this sweep measures what is left: for white-n
 origins `dist` object units away it counts rays where the GPU, the oracle's hierarchical walk and the oracle's band
 brute force disagree, and resolves each disagreement with the FULL brute force (every triangle of the field).
 
-usage (GPU box):  python tests/tools/far_origin_sweep.py [rays_per_case]
+usage (GPU box):  python tests/tools/far_origin_sweep.py [rays_per_case [dump_dir]]   (dump_dir: the disagreeing rays as .npz)
 """
 import os
 import sys
@@ -21,7 +21,7 @@ import hf_amd                                 # noqa: E402  (tests/hf_amd.py: th
 from oracle import hf_oracle as O             # noqa: E402
 
 
-def main(n=400000, cap=64):
+def main(n=400000, cap=64, dump=None):
     O.build()
     rng = np.random.default_rng(1)
     nt = min(16, os.cpu_count() or 1)
@@ -43,10 +43,17 @@ def main(n=400000, cap=64):
         bad = np.nonzero(gb | wb)[0][:cap]
         line = f"{N} {dist} {mh} | {n} | {int(gb.sum())} {int(wb.sum())} {int(gw.sum())}"
         if bad.size:
-            _, _, _, pn = f.ray_intersect_preliminary(np.ascontiguousarray(r[:, bad]), naive=True, nthreads=nt)
+            tn, _, _, pn = f.ray_intersect_preliminary(np.ascontiguousarray(r[:, bad]), naive=True, nthreads=nt)
             line += f" | {bad.size}: {int((pn == pb[bad]).sum())} {int((pn == pg[bad]).sum())} {int((pn == pw[bad]).sum())}"
+            if dump:   # the disagreeing rays with every checker's answer (regression vectors: tests/test_oracle_band.py)
+                os.makedirs(dump, exist_ok=True)
+                np.savez(os.path.join(dump, f"far_origin_N{N}_d{dist}.npz"), index=bad, rays=r[:, bad], full_prim=pn, full_t=tn,
+                         band_prim=pb[bad], walk_prim=pw[bad], gpu_prim=pg[bad])
+                lost = bad[(pn != pw[bad]) | (pn != pg[bad])]
+                if lost.size:
+                    line += f" | walk or GPU != full on rays {lost.tolist()}"
         print(line, flush=True)
 
 
 if __name__ == "__main__":
-    main(int(sys.argv[1]) if len(sys.argv) > 1 else 400000)
+    main(int(sys.argv[1]) if len(sys.argv) > 1 else 400000, dump=sys.argv[2] if len(sys.argv) > 2 else None)
