@@ -14,7 +14,10 @@ SOURCES = ["hf_kernels.hip", "hf_capi.cpp"]
 HEADERS = ["hf_device.h", "hf_launch.h", os.path.join("..", "..", "include", "hf.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
          # spec arithmetic: only the fma calls written in the source may fuse
-         "-ffp-contract=off", "-fno-fast-math", "-Wno-bitwise-instead-of-logical", "-Wno-unused-function"]
+         "-ffp-contract=off", "-fno-fast-math", "-Wno-bitwise-instead-of-logical", "-Wno-unused-function",
+         # no SLP vectoriser: its v_pk_* pairs need aligned register pairs and cost these kernels 2-10 spilled registers
+         # (traversal) and 20-30 VGPRs (adjoint 88 -> 66, SI 76 -> 59); same IEEE results (profiles/r04_ab/r04_item3)
+         "-fno-slp-vectorize"]
 
 
 def _hipcc():

@@ -208,6 +208,7 @@ extern "C" int hf_create(const hf_desc_t *desc, hf_field_t **out) {
     d.s = desc->max_height;
     d.sx = 2.0f / (float) (d.W - 1); d.sy = 2.0f / (float) (d.H - 1);
     d.iu = 1.0f / (float) (d.W - 1); d.iv = 1.0f / (float) (d.H - 1);
+    d.hx = 0.5f * (float) (d.W - 1); d.hy = 0.5f * (float) (d.H - 1);
     d.flip = desc->flip_normals ? 1 : 0;
     int rc = set_transform(hf, desc->to_world, desc->has_to_object ? desc->to_object : nullptr);
     if (rc != HF_OK) { free(hf); return rc; }

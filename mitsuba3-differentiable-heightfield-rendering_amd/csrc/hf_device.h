@@ -79,6 +79,7 @@ struct hf_dev_field {
     int32_t W, H;
     int32_t top;  // max(ceil(log2(max(W-1,H-1))), 1); mip[1] is the global (min,max)
     float s, sx, sy, iu, iv;
+    float hx, hy; // 0.5 (W - 1), 0.5 (H - 1): cells per object unit (host-computed: a kernarg scalar instead of a hoisted -- and spilled -- vector register)
     int32_t flip;
     float to_world[12], to_object[12];
 };

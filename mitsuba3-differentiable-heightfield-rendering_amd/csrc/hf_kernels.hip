@@ -105,13 +105,17 @@ __global__ __launch_bounds__(HF_BLOCK) void hf_shear_kernel(const float *__restr
     rmax = fmaxf(rmax, __shfl_xor(rmax, 1));
     rmax = fmaxf(rmax, __shfl_xor(rmax, 2));
     float *rec = (float *) (out + (size_t) node * 3);
-    if (j == 0) { rec[0] = a; rec[1] = b; rec[2] = c; rec[3] = __builtin_fabsf(a) + __builtin_fabsf(b) + fmaxf(rmax, 0.f); }
+    if (j == 0) { rec[0] = a; rec[1] = b; rec[2] = c; rec[3] = __builtin_fabsf(a) + __builtin_fabsf(b) + 2.f * fmaxf(rmax, 0.f); }
     rec[4 + 2 * j] = lo; rec[5 + 2 * j] = hi;
 }
 // Fourth entry of the record: what the walk multiplies its xy uncertainty m by to get a z uncertainty -- the slope
-// of the plane, |a|+|b| per cell, PLUS the largest sheared range of a child: the triangle test may report a hit up
-// to m cells beside the walk's ray (that is what m stands for), and where the surface is far steeper than the plane
-// (a needle triangle) those m cells are up to m x range up or down.
+// of the plane, |a|+|b| per cell, PLUS TWICE the largest sheared range of a child: the triangle test may report a hit
+// up to m cells beside the walk's ray (that is what m stands for), and where the surface is far steeper than the plane
+// (a needle triangle) those m cells are up to m x (|dw/dx| + |dw/dy|) up or down, each partial derivative of a triangle
+// bounded by the sheared range of its cell, hence of the child that holds it.  (One range until round 4: the full brute
+// force over 16.7 M cells -- found through the oracle walk once IT carried the factor two -- reports a noise hit at
+// N = 4096 from 8 units away that (|a|+|b|+r) m fell short of: tests/test_gpu_band.py::
+// test_walk_needle_term_regression_on_the_gpu.)
 // (computed by hf_shear_kernel / hf_shear_level1_kernel with the ranges.)
 
 // Level 1 (three quarters of all records, 201 MB at N = 4096): one thread per node -- the 3x3 vertex window is read
@@ -168,7 +172,7 @@ __global__ __launch_bounds__(HF_BLOCK) void hf_shear_level1_kernel(const float *
     }
     const float rmax = fmaxf(fmaxf(fmaxf(hi[0] - lo[0], hi[1] - lo[1]), fmaxf(hi[2] - lo[2], hi[3] - lo[3])), 0.f); // absent: -inf
     float4 *rec = out + (size_t) node * 3;
-    rec[0] = make_float4(a, b, c, __builtin_fabsf(a) + __builtin_fabsf(b) + rmax);
+    rec[0] = make_float4(a, b, c, __builtin_fabsf(a) + __builtin_fabsf(b) + 2.f * rmax);
     rec[1] = make_float4(lo[0], hi[0], lo[1], hi[1]);
     rec[2] = make_float4(lo[2], hi[2], lo[3], hi[3]);
 }
@@ -182,7 +186,7 @@ __global__ __launch_bounds__(HF_BLOCK) void hf_shear_level1_kernel(const float *
 // below it -- which the fitted-plane records carry too; absent children (+inf, -inf) do not count.
 __device__ __forceinline__ float4 hf_minmax_plane(float2 a, float2 b, float2 d, float2 e) {
     const float r = fmaxf(fmaxf(fmaxf(a.y - a.x, b.y - b.x), fmaxf(d.y - d.x, e.y - e.x)), 0.f);
-    return make_float4(0.f, 0.f, 0.f, r);
+    return make_float4(0.f, 0.f, 0.f, 2.f * r);
 }
 __global__ __launch_bounds__(HF_BLOCK) void hf_shear_minmax_kernel(const float2 *__restrict__ child, int sh,
                                                                   float4 *__restrict__ out) {
@@ -383,7 +387,7 @@ __device__ __forceinline__ bool setup_ray(const hf_dev_field &f, float2 zr, v3 o
         if (!(__builtin_fabsf(chk) < __builtin_inff()) || !(maxt >= 0.f)) return false;
     }
     const int cw = f.W - 1, ch = f.H - 1, top = f.top;
-    const float hx = 0.5f * (float) cw, hy = 0.5f * (float) ch;
+    const float hx = f.hx, hy = f.hy; // 0.5 (W - 1), 0.5 (H - 1)
     const float zspan = fmaxf(zr.y - zr.x, fmaxf(__builtin_fabsf(zr.x), __builtin_fabsf(zr.y)));
     const float mz0 = 1e-5f * zspan + 1e-30f;
 
@@ -428,7 +432,7 @@ __device__ __forceinline__ bool setup_ray(const hf_dev_field &f, float2 zr, v3 o
     {
         // (sx = 1 / hx: a cell.  Multiply + add, not fma and not m / hx: the two divisions cost the launch 2 %, and with
         // the fused form the fused kernel spills 6 registers instead of 2)
-        const float ex = 1e-4f + m * f.sx, ey = 1e-4f + m * f.sy, ez = __builtin_fmaf(m, zspan, mz0);
+        const float ex = 1e-4f + m * f.sx, ey = 1e-4f + m * f.sy, ez = __builtin_fmaf(2.f * m, zspan, mz0);
         const float lo[3] = { -1.f - ex, -1.f - ey, zr.x - ez };
         const float hi[3] = { 1.f + ex, 1.f + ey, zr.y + ez };
         bool outside = false;
@@ -476,18 +480,22 @@ __device__ __forceinline__ bool setup_ray(const hf_dev_field &f, float2 zr, v3 o
 // axis into order space flips the sign of its slope.  mz grows by the slope times the xy uncertainty
 // of the walk (the margin m) plus the rounding of the line itself, whose terms are as large as
 // slope x grid size.
-__device__ __forceinline__ void shear_line(const hf_dev_field &f, const hf_ray_state &rs, bool fx, bool fy, float a,
-                                           float b, float c, float sab, float xc, float yc, float &gz, float &dz,
-                                           float &mz) {
-    const hf_trav &r = rs.r;
+__device__ __forceinline__ void shear_line_v(const hf_trav &r, float dxo, float dyo, float eps_top, bool fx, bool fy, float a,
+                                             float b, float c, float sab, float xc, float yc, float &gz, float &dz, float &mz) {
     const float ao = fx ? -a : a, bo = fy ? -b : b;
     const float ux = 0.5f * (r.gxm + r.gxp) - xc, uy = 0.5f * (r.gym + r.gyp) - yc;
     gz = __builtin_fmaf(-bo, uy, __builtin_fmaf(-ao, ux, r.gz - c));
-    const float dxo = __builtin_fabsf(rs.od.x) * (0.5f * (float) (f.W - 1));
-    const float dyo = __builtin_fabsf(rs.od.y) * (0.5f * (float) (f.H - 1));
     dz = __builtin_fmaf(-bo, dyo, __builtin_fmaf(-ao, dxo, r.dz));
-    const float m = 0.5f * (r.gxm - r.gxp) + HF_LINE_EPS * (float) (1 << f.top);
+    const float m = 0.5f * (r.gxm - r.gxp) + eps_top;
     mz = __builtin_fmaf(sab, m, r.mz);
+}
+// (dxo, dyo: the xy direction in cells per unit of t, order space; eps_top = HF_LINE_EPS x the grid's side)
+__device__ __forceinline__ void shear_line(const hf_dev_field &f, const hf_ray_state &rs, bool fx, bool fy, float a,
+                                           float b, float c, float sab, float xc, float yc, float &gz, float &dz,
+                                           float &mz) {
+    const float dxo = __builtin_fabsf(rs.od.x) * f.hx;
+    const float dyo = __builtin_fabsf(rs.od.y) * f.hy;
+    shear_line_v(rs.r, dxo, dyo, HF_LINE_EPS * (float) (1 << f.top), fx, fy, a, b, c, sab, xc, yc, gz, dz, mz);
 }
 
 // actual-child mask -> order-space child mask (bit k = bit (k ^ flip))
@@ -743,6 +751,145 @@ __device__ __forceinline__ float wave_min16(const float (&h)[16], uint32_t lane,
     return v;
 }
 
+// ---------------------------------------------------------------------------------
+// ITEM WALK (round 4): the subtree below a hand-off node as a wave-wide work list instead of 64 private depth-first walks.
+// The per-lane walk leaves most of the wave idle -- a visit runs with 19 of 64 lanes, a cell round with 13 -- because every
+// converged round lasts until its slowest lane has made its step, and a lane's steps are a dependent chain (rays that
+// skim the surface crawl from 2x2-cell node to node).  Here a unit of work is an ITEM (ray, node) or (ray, cell) on a
+// stack in the wave's LDS: the lanes that take the hand-off node push their children, and every round the wave pops up
+// to 64 items of ONE level from the top of the stack -- any lane takes any item: it pulls the ray's traversal constants
+// from the owning lane's registers (ds_bpermute, no copy of the ray in LDS), evaluates the node's record exactly as a
+// per-lane visit does (same shear_line / child_mask arithmetic), and pushes the children that pass (ballot + mbcnt
+// prefix per child slot); a cell item runs the two-triangle test and merges its hit into the ray's entry of an LDS table
+// with one 64-bit minimum -- key = (t bits, ~prim_index): the closest hit, the higher primitive on a tie, the order the
+// brute force produces (kdtree.h:2424-2448).  A crawling ray's chain is thereby spread over the idle lanes level by
+// level: the depth of the work list below a 16x16-cell node is four rounds whatever the slowest ray does.  What is lost
+// is front-to-back pruning between the children of one node (they are all pushed; t_hi only takes effect on the next
+// pop, after a cell round) -- harmless for the result (a minimum over a superset of the cells) and cheap while the
+// extra items ride in lanes that would have idled.
+// Stack discipline: items are pushed far child first, popped from the top; a round takes the run of equal-level items
+// on top (so a round is either all visits or all cell tests), at most 64, and fewer when the children it may push (four
+// per item) would not fit -- down to one item per round, which is a plain depth-first walk whose stack grows by at
+// most three per level, so HF_ITEM_CAP is never exceeded whatever the rays do.
+#ifndef HF_ITEM_WALK
+#define HF_ITEM_WALK 1
+#endif
+#define HF_ITEM_CAP 512
+struct hf_items_lds {
+    unsigned long long best[64]; // per ray of the batch: (t bits << 32) | ~prim_index of its closest hit so far; all ones = none
+    float2 uv[64];               // barycentrics of that hit
+    uint32_t stack[HF_ITEM_CAP]; // items: x | y << 4 (node / cell relative to the hand-off node, order space) | level << 8 | ray << 10
+};
+__device__ __forceinline__ float bperm_f(int src4, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src4, __builtin_bit_cast(int, v)));
+}
+__device__ __forceinline__ uint32_t mbcnt64(uint64_t m) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, 0u));
+}
+// children (order-space mask m4) of the item's node -> items of level lv - 1, far child first; `on` lanes push
+__device__ __forceinline__ void push_children(hf_items_lds *q, uint32_t &count, bool on, uint32_t m4, uint32_t ray, uint32_t lvc,
+                                              uint32_t x2, uint32_t y2) {
+#pragma unroll
+    for (int k = 3; k >= 0; --k) {
+        const bool b = on && ((m4 >> k) & 1u) != 0u;
+        const uint64_t bm = __ballot(b);
+        if (b) q->stack[count + mbcnt64(bm)] = (x2 + (uint32_t) (k & 1)) | ((y2 + (uint32_t) (k >> 1)) << 4) | (lvc << 8) | (ray << 10);
+        count += (uint32_t) __builtin_popcountll(bm);
+    }
+}
+// All 64 lanes call this (wave-uniform control flow).  (nX, nY): order-space coordinates of the hand-off node (level
+// HF_SUBTREE_LEVEL), wave-uniform; cur0: this lane's order-space children of it to visit (0: the lane does not take the node).
+template <bool ANY>
+__device__ __forceinline__ void walk_items(const hf_dev_field &f, const hf_ray_state &rs, float dxo, float dyo, bool fx, bool fy,
+                                           uint32_t nX, uint32_t nY, uint32_t cur0, float &thi, hf_items_lds *q, uint32_t lane) {
+    const hf_trav &r = rs.r;
+    const int top = f.top;
+    const uint32_t fxm = fx ? ((1u << top) - 1u) : 0u, fym = fy ? ((1u << top) - 1u) : 0u;
+    uint32_t count = 0u; // items on the stack (wave-uniform)
+    push_children(q, count, cur0 != 0u, cur0, lane, (uint32_t) (HF_SUBTREE_LEVEL - 1), 0u, 0u);
+    while (count != 0u) { // wave-uniform
+        WCOUNT(3);
+        __builtin_amdgcn_wave_barrier(); // (same wave: LDS operations stay in order; this keeps the compiler from reordering them)
+        // ---- the run of equal-level items on top of the stack ----
+        const bool has = lane < count;
+        const uint32_t it = has ? q->stack[count - 1u - lane] : 0xFFFFFFFFu;
+        const uint32_t lv = (uint32_t) __builtin_amdgcn_readfirstlane((int) ((it >> 8) & 3u));
+        const uint64_t diff = ~__ballot(has && ((it >> 8) & 3u) == lv);
+        uint32_t n = diff == 0ull ? 64u : (uint32_t) __builtin_ctzll(diff);
+        if (lv != 0u) { // room for four children per item (see above); always at least one item
+            const uint32_t room = (uint32_t) HF_ITEM_CAP - 12u - count; // count <= HF_ITEM_CAP - 3 always
+            const uint32_t fit = (int32_t) room > 0 ? room / 3u : 0u;
+            n = min(n, max(fit, 1u));
+        }
+        const bool mine = lane < n;
+        count -= n;
+        const uint32_t ray = mine ? (it >> 10) & 63u : lane;
+        const int src4 = (int) (ray << 2);
+        const uint32_t x = it & 15u, y = (it >> 4) & 15u;
+        if (lv != 0u) {
+            // ---- visits: node (X, Y) of level lv, for the ray of lane `ray` ----
+            hf_trav rr;
+            rr.gxm = bperm_f(src4, r.gxm); rr.gxp = bperm_f(src4, r.gxp); rr.gym = bperm_f(src4, r.gym); rr.gyp = bperm_f(src4, r.gyp);
+            rr.gz = bperm_f(src4, r.gz); rr.dz = bperm_f(src4, r.dz); rr.idx = bperm_f(src4, r.idx); rr.idy = bperm_f(src4, r.idy);
+            rr.mz = bperm_f(src4, r.mz);
+            const float rdxo = bperm_f(src4, dxo), rdyo = bperm_f(src4, dyo), rthi = bperm_f(src4, thi);
+            uint32_t m4 = 0u;
+            if (mine) {
+                const uint32_t X = (nX << ((uint32_t) HF_SUBTREE_LEVEL - lv)) + x, Y = (nY << ((uint32_t) HF_SUBTREE_LEVEL - lv)) + y;
+                const float S = (float) (1u << lv), Sc = 0.5f * S;
+                // the item may predate a hit: its entry against the ray's current t_hi
+                const float te = fmaxf(((float) X * S - rr.gxm) * rr.idx, ((float) Y * S - rr.gym) * rr.idy);
+                if (te <= rthi && (!ANY || rthi >= 0.f)) { // (any hit: a ray that has hit holds t_hi = -1)
+                    WCOUNT(5); WLANES(7, 0); WHIST(11);
+                    const uint32_t ix = X ^ (fxm >> lv), iy = Y ^ (fym >> lv);
+                    const uint32_t k = (uint32_t) top - lv;
+                    const float4 *rec = f.shear + (size_t) (hf_depth_off((int) k) - 1u + (iy << k) + ix) * 3;
+                    const float4 pl = rec[0], q01 = rec[1], q23 = rec[2];
+                    float gz, dz, mz;
+                    shear_line_v(rr, rdxo, rdyo, HF_LINE_EPS * (float) (1 << top), fx, fy, pl.x, pl.y, pl.z, pl.w,
+                                 __builtin_fmaf((float) X, S, Sc), __builtin_fmaf((float) Y, S, Sc), gz, dz, mz);
+                    hf_quad qd;
+                    qd.lo[0] = q01.x; qd.hi[0] = q01.y; qd.lo[1] = q01.z; qd.hi[1] = q01.w;
+                    qd.lo[2] = q23.x; qd.hi[2] = q23.y; qd.lo[3] = q23.z; qd.hi[3] = q23.w;
+                    m4 = to_order(child_mask(rr, fx, fy, (float) X * S, (float) Y * S, Sc, qd, gz, dz, mz, rthi), fx, fy);
+                }
+            }
+            push_children(q, count, mine, m4, ray, lv - 1u, 2u * x, 2u * y);
+        } else {
+            // ---- cell tests: cell (x, y) of the hand-off node, for the ray of lane `ray` ----
+            const v3 oo = mk3(bperm_f(src4, rs.oo.x), bperm_f(src4, rs.oo.y), bperm_f(src4, rs.oo.z));
+            const v3 od = mk3(bperm_f(src4, rs.od.x), bperm_f(src4, rs.od.y), bperm_f(src4, rs.od.z));
+            const float rmaxt = bperm_f(src4, rs.maxt);
+            const float rthi = ANY ? bperm_f(src4, thi) : 0.f;
+            hf_hit b;
+            b.hit = false; b.t = __builtin_inff(); b.u = 0.f; b.v = 0.f; b.prim = 0u;
+            unsigned long long key = ~0ull;
+            if (mine && (!ANY || rthi >= 0.f)) {
+                WCOUNT(6); WLANES(7, 16); WHIST(8);
+                const int cxx = (int) (((nX << HF_SUBTREE_LEVEL) + x) ^ fxm), cyy = (int) (((nY << HF_SUBTREE_LEVEL) + y) ^ fym);
+                const uint32_t off = ((uint32_t) cyy * (uint32_t) f.W + (uint32_t) cxx) << 2, pitch = (uint32_t) f.W << 2;
+                const char *hb = (const char *) f.h;
+                const float z00 = *(const float *) (hb + off) * f.s, z10 = *(const float *) (hb + off + 4u) * f.s;
+                const float z01 = *(const float *) (hb + off + pitch) * f.s, z11 = *(const float *) (hb + off + pitch + 4u) * f.s;
+                if (test_cell(f, cxx, cyy, z00, z10, z01, z11, oo, od, rmaxt, b)) {
+                    key = ((unsigned long long) __builtin_bit_cast(uint32_t, b.t) << 32) | (unsigned long long) (~b.prim);
+                    atomicMin(&q->best[ray], key);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (b.hit && q->best[ray] == key) q->uv[ray] = make_float2(b.u, b.v); // the (unique) winner's barycentrics
+            __builtin_amdgcn_wave_barrier();
+            // every lane: its own ray's closest hit so far bounds what is left of its segment
+            const unsigned long long mk = q->best[lane];
+            if (mk != ~0ull) {
+                float tb = __builtin_bit_cast(float, (uint32_t) (mk >> 32)) - rs.tin;
+                tb = tb + __builtin_fabsf(tb) * 1e-6f + 1e-30f;
+                thi = ANY ? -1.f : fminf(thi, tb);
+            }
+        }
+    }
+}
+
 // Coherent wave, upper levels by BEAM SWEEP.  The row sweep above pays per enumerated node: a uniform (scalar) load of
 // its box, whose latency nothing hides, a per-lane box test and a ballot -- 16.8 nodes per batch of which 4.2 are
 // entered, and 7.8 rows with two wave reductions each: a fifth of a traversing batch's instructions.  Here the
@@ -773,8 +920,8 @@ enum { BM_ISN, BM_ISX, BM_ICN, BM_ICX, BM_AS, BM_BS, BM_AC, BM_BC, BM_GCLO, BM_G
 // out over a long path) -- at the start or between two passes: the caller then lets every live lane walk from the
 // root with the t_hi and the best hit reached so far (re-testing a cell is harmless: the result is a minimum).
 template <bool ANY>
-__device__ __forceinline__ bool walk_beam(const hf_dev_field &f, const hf_ray_state &rs, bool alive, bool fx, bool fy,
-                                          hf_hit &best, float &thi, hf_beam_lds *lds) {
+__device__ __forceinline__ bool walk_beam_impl(const hf_dev_field &f, const hf_ray_state &rs, bool alive, bool fx, bool fy,
+                                               hf_hit &best, float &thi, hf_beam_lds *lds, hf_items_lds *items) {
     const hf_trav &r = rs.r;
     // (opaque copies: everything derived from the lane number or the level count is loop-invariant for the kernel's
     // persistent loop, and the compiler would compute it all at kernel entry and then spill it -- 30 registers)
@@ -785,7 +932,7 @@ __device__ __forceinline__ bool walk_beam(const hf_dev_field &f, const hf_ray_st
     const uint32_t kd = (uint32_t) (top - HF_SUBTREE_LEVEL), nn = 1u << kd;
     const float S = (float) (1u << HF_SUBTREE_LEVEL), iS = 1.0f / S, lim = (float) nn - 0.5f;
     const float inf = __builtin_inff();
-    const float dxo = __builtin_fabsf(rs.od.x) * (0.5f * (float) (f.W - 1)), dyo = __builtin_fabsf(rs.od.y) * (0.5f * (float) (f.H - 1));
+    const float dxo = __builtin_fabsf(rs.od.x) * f.hx, dyo = __builtin_fabsf(rs.od.y) * f.hy;
     // slab axis s / cross axis c (wave-uniform choice from the first live lane; any choice is correct)
     const int first = __builtin_ctzll(__ballot(alive));
     const bool xm = __builtin_amdgcn_readlane((int) (dxo > dyo), first) != 0;
@@ -856,7 +1003,7 @@ __device__ __forceinline__ bool walk_beam(const hf_dev_field &f, const hf_ray_st
                 float u0 = fmaxf(fmaxf(fS * isn - as, fC * icn - ac), 0.f), u1 = fminf(fminf((fS + S) * isx - bs, (fC + S) * icx - bc), T);
                 u0 = fmaxf(u0 - (1e-5f * u0 + 1e-5f), 0.f); u1 = u1 + (1e-5f * u1 + 1e-5f);
                 const float za = zlo + fminf(u0 * dzn, u1 * dzn), zb = zhi + fmaxf(u0 * dzx, u1 * dzx);
-                const float zs = __builtin_fmaf(lds->hdr[16], box.y - box.x, 1e-5f * (__builtin_fabsf(za) + __builtin_fabsf(zb)) + 1e-30f);
+                const float zs = __builtin_fmaf(2.f * lds->hdr[16], box.y - box.x, 1e-5f * (__builtin_fabsf(za) + __builtin_fabsf(zb)) + 1e-30f);
                 cand = (u0 <= u1) & (za - zs <= box.y) & (zb + zs >= box.x);
                 if (cand) {
                     lds->e[lane].box = make_float4(box.x, box.y, 0.f, 0.f);
@@ -888,7 +1035,7 @@ __device__ __forceinline__ bool walk_beam(const hf_dev_field &f, const hf_ray_st
                 const float ylo = (fYc - r.gym) * r.idy, yhi = (fYc + S - r.gyp) * r.idy;
                 const float u0 = fmaxf(fmaxf(xlo, ylo), 0.f), u1 = fminf(fminf(xhi, yhi), thi);
                 const float za = __builtin_fmaf(u0, r.dz, r.gz), zb = __builtin_fmaf(u1, r.dz, r.gz);
-                const float bz = __builtin_fmaf(rs.m, cbox.y - cbox.x, r.mz);
+                const float bz = __builtin_fmaf(2.f * rs.m, cbox.y - cbox.x, r.mz); // needle term: 2 m x (range), see hf_shear_kernel
                 const bool mine = (u0 <= u1) & (fminf(za, zb) - bz <= cbox.y) & (fmaxf(za, zb) + bz >= cbox.x);
                 if (__ballot(mine) == 0ull) {
                     // nobody overlaps this node; done when nobody can reach its slab -- or any later one -- before its t_hi
@@ -940,11 +1087,18 @@ __device__ __forceinline__ bool walk_beam(const hf_dev_field &f, const hf_ray_st
                     pre_v = wcnt_base()[5]; pre_c = wcnt_base()[6];
                 }
 #endif
+#if HF_ITEM_WALK
+                {   // the node as a wave-wide work list (walk_items): every lane takes part, the holders push their children
+                    const uint32_t hn = (uint32_t) __builtin_amdgcn_readlane((int) held, __builtin_ctzll(__ballot(held != 0u)));
+                    walk_items<ANY>(f, rs, dxo, dyo, fx, fy, hn & 0xFFFu, (hn >> 12) & 0xFFFu, held >> 24, thi, items, lane);
+                }
+#else
                 if (held != 0u) {
                     const bool h = walk_subtree_from<ANY>(f, src, rs, r, rs.fx, rs.fy, lfxm, lfym, held & 0xFFFu, (held >> 12) & 0xFFFu,
                                                           HF_SUBTREE_LEVEL, held >> 24, thi, best);
                     if (ANY && h) thi = -1.f;
                 }
+#endif
 #if defined(HF_WSTATS) && HF_WSTATS == 2
                 if (tail && lane == 0u) { uint32_t *c = wcnt_base(); c[8] += c[5] - pre_v; c[9] += c[6] - pre_c; c[10]++; }
 #endif
@@ -960,6 +1114,30 @@ __device__ __forceinline__ bool walk_beam(const hf_dev_field &f, const hf_ray_st
         if (__ballot(tsn <= thi) == 0ull) break;
     }
     return true;
+}
+
+// the beam sweep with the item walk's hit table around it: cleared before, folded into `best` after (every exit)
+template <bool ANY>
+__device__ __forceinline__ bool walk_beam(const hf_dev_field &f, const hf_ray_state &rs, bool alive, bool fx, bool fy,
+                                          hf_hit &best, float &thi, hf_beam_lds *lds, hf_items_lds *items) {
+#if HF_ITEM_WALK
+    const uint32_t lane = threadIdx.x & 63u;
+    {   // (opaque: the pair of all-ones registers is otherwise hoisted out of the kernel's persistent loop and spilled)
+        uint32_t ones = 0xFFFFFFFFu;
+        asm volatile("" : "+v"(ones));
+        items->best[lane] = ((unsigned long long) ones << 32) | (unsigned long long) ones;
+    }
+#endif
+    const bool done = walk_beam_impl<ANY>(f, rs, alive, fx, fy, best, thi, lds, items);
+#if HF_ITEM_WALK
+    __builtin_amdgcn_wave_barrier();
+    const unsigned long long mk = items->best[lane];
+    if (mk != ~0ull) {
+        const float2 uv = items->uv[lane];
+        best_update(best, __builtin_bit_cast(float, (uint32_t) (mk >> 32)), uv.x, uv.y, ~(uint32_t) mk);
+    }
+#endif
+    return done;
 }
 
 // ---------------------------------------------------------------------------------
@@ -1073,7 +1251,7 @@ __device__ __forceinline__ hf_dev_field load_field(const __attribute__((address_
     hf_dev_field f;
     f.h = p->h; f.mip = p->mip; f.shear = p->shear;
     f.W = p->W; f.H = p->H; f.top = p->top;
-    f.s = p->s; f.sx = p->sx; f.sy = p->sy; f.iu = p->iu; f.iv = p->iv; f.flip = p->flip;
+    f.s = p->s; f.sx = p->sx; f.sy = p->sy; f.iu = p->iu; f.iv = p->iv; f.hx = p->hx; f.hy = p->hy; f.flip = p->flip;
 #pragma unroll
     for (int k = 0; k < 12; ++k) { f.to_world[k] = p->to_world[k]; f.to_object[k] = p->to_object[k]; }
     return f;
@@ -1137,6 +1315,7 @@ __global__ __launch_bounds__(HF_BLOCK, (MODE == 2 ? HF_TRACE_WAVES_FUSED : HF_TR
     const hf_dev_field &f = a.f;
     const unsigned lane = threadIdx.x & 63u;
     __shared__ hf_beam_lds s_beam[HF_BLOCK / 64]; // per wave: the beam and box + record of the pass's nodes (walk_beam)
+    __shared__ hf_items_lds s_items[HF_BLOCK / 64]; // per wave: work list and hit table of the item walk (walk_items)
     // Work distribution: the wavefront is cut into grabs of `grab` consecutive rays; XCD x owns grabs x, x + 8, ...
     // and hands them out through its own counter (a single counter serves ~80 fetches/us, which capped the rays
     // that only stream at half the memory bandwidth; eight addresses are served in parallel).  A wave pulls from the
@@ -1238,7 +1417,7 @@ __global__ __launch_bounds__(HF_BLOCK, (MODE == 2 ? HF_TRACE_WAVES_FUSED : HF_TR
                 bool root = alive;
                 wstats_reset();
                 if (coherent && f.top > HF_SUBTREE_LEVEL)
-                    root = !walk_beam<MODE == 1>(f, rs, alive, fx0, fy0, best, thi, &s_beam[threadIdx.x >> 6]) && alive && thi >= 0.f;
+                    root = !walk_beam<MODE == 1>(f, rs, alive, fx0, fy0, best, thi, &s_beam[threadIdx.x >> 6], &s_items[threadIdx.x >> 6]) && alive && thi >= 0.f;
                 if (root) {
                     hf_src_global src;
                     src.mip = f.mip; src.shear = f.shear; src.h = f.h; src.top = f.top; src.W = f.W;

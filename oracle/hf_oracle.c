@@ -352,7 +352,7 @@ static void trace_hier(const hfo_field *f, const float o[3], const float d[3], f
     const float m = 0.00390625f + fminf(8.f, 4.8e-7f * reach * fmaxf(hx, hy) * (far * far));
     float tin = 0.f, tout = maxt;
     {
-        const float ex = 1e-4f + m * f->sx, ey = 1e-4f + m * f->sy, ez = fmaf(m, zspan, mz0); /* (sx = 1 / hx: a cell) */
+        const float ex = 1e-4f + m * f->sx, ey = 1e-4f + m * f->sy, ez = fmaf(2.f * m, zspan, mz0); /* (sx = 1 / hx: a cell; 2 m: as the node tests) */
         const float lo[3] = { -1.f - ex, -1.f - ey, f->zmin - ez };
         const float hi[3] = {  1.f + ex,  1.f + ey, f->zmax + ez };
         for (int k = 0; k < 3; ++k) {

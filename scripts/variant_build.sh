@@ -10,6 +10,6 @@ sed "$expr" csrc/hf_kernels.hip > csrc/_variant_$name.hip
 diff -u csrc/hf_kernels.hip csrc/_variant_$name.hip > ../profiles/variants/$name.diff || true
 { echo "# flags: $*"; echo "# base: $(git rev-parse --short HEAD)"; } >> ../profiles/variants/$name.diff
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fno-fast-math \
-  -Wno-bitwise-instead-of-logical -Wno-unused-function "$@" -I ../include csrc/_variant_$name.hip csrc/hf_capi.cpp -ldl \
+  -Wno-bitwise-instead-of-logical -Wno-unused-function -fno-slp-vectorize "$@" -I ../include csrc/_variant_$name.hip csrc/hf_capi.cpp -ldl \
   -o ../scratch_so/libhf_$name.so
 rm -f csrc/_variant_$name.hip

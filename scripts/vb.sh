@@ -8,5 +8,5 @@ name=$1; shift
 mkdir -p ../scratch_so ../profiles/variants
 echo "base $(git rev-parse --short HEAD)$(git diff --quiet -- csrc || echo '+dirty') flags: $*" > ../profiles/variants/$name.flags
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fno-fast-math \
-  -Wno-bitwise-instead-of-logical -Wno-unused-function "$@" -I ../include csrc/hf_kernels.hip csrc/hf_capi.cpp -ldl \
+  -Wno-bitwise-instead-of-logical -Wno-unused-function -fno-slp-vectorize "$@" -I ../include csrc/hf_kernels.hip csrc/hf_capi.cpp -ldl \
   -o ../scratch_so/libhf_$name.so

@@ -166,5 +166,7 @@ def test_walk_needle_term_regression_on_the_gpu(hf, oracle):
     for copies in (64, 1):
         rt = torch.from_numpy(np.repeat(r, copies, 1)).cuda()
         pi = shape.ray_intersect_preliminary(hf.Ray3f(rt[0:3].contiguous(), rt[3:6].contiguous(), rt[6].contiguous()))
-        assert np.array_equal(pi.prim_index.cpu().numpy().view(np.uint32), np.repeat(prim, copies))
+        got = pi.prim_index.cpu().numpy().view(np.uint32).reshape(6, copies)
+        assert np.array_equal(got, np.repeat(prim, copies).reshape(6, copies)), \
+            f"rays {np.nonzero((got != prim[:, None]).any(1))[0].tolist()} of the six differ from the full brute force: {got[:, 0].tolist()} vs {prim.tolist()}"
         assert np.array_equal(pi.t.cpu().numpy().view(np.uint32), np.repeat(t.view(np.uint32), copies))
