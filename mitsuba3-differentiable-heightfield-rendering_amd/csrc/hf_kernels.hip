@@ -315,6 +315,25 @@ __device__ __forceinline__ void wstats_reset() { if ((threadIdx.x & 63u) < 16u) 
 __device__ __forceinline__ void wstats_reset() { }
 #endif
 
+#ifdef HF_TSTATS
+// Cycle stamps (diagnostic build, scripts/tstats.py): TSTAMP(k) adds the shader cycles since the previous stamp of the
+// wave to phase k of the batch (lane 0 keeps the books in LDS; each stamp costs an s_memtime and three LDS operations);
+// at the end of a batch with live lanes, lane l < 16 reports phase l in place of its hit record.
+__device__ __forceinline__ uint32_t *tcnt_base() {
+    __shared__ uint32_t c[HF_BLOCK / 64][16];
+    return c[threadIdx.x >> 6];
+}
+#define TSTART() do { __builtin_amdgcn_wave_barrier(); if ((threadIdx.x & 63u) == 0u) { uint32_t *c_ = tcnt_base(); \
+        const uint32_t now_ = (uint32_t) clock64(), out_ = now_ - c_[15]; /* since the last stamp of the wave's previous batch: its output phase */ \
+        for (int i_ = 0; i_ < 15; ++i_) c_[i_] = 0u; c_[8] = out_; c_[15] = now_; } __builtin_amdgcn_wave_barrier(); } while (0)
+#define TSTAMP(k) do { if ((threadIdx.x & 63u) == 0u) { uint32_t *c_ = tcnt_base(); const uint32_t now_ = (uint32_t) clock64(); \
+        c_[k] += now_ - c_[15]; c_[15] = now_; } } while (0)
+#define TSTATS_EXPORT(any_alive, valid, best) do { __builtin_amdgcn_wave_barrier(); if ((any_alive) && (valid)) { (best).hit = true; \
+        (best).t = (float) tcnt_base()[threadIdx.x & 15u]; (best).u = 0.f; (best).v = 0.f; (best).prim = threadIdx.x & 63u; } } while (0)
+#else
+#define TSTART() do { } while (0)
+#define TSTAMP(k) do { } while (0)
+#endif
 #ifndef HF_M0
 #define HF_M0 0.00390625f // constant part of the xy margin, cells (1/64 until round 3: see setup_ray)
 #endif
@@ -752,33 +771,39 @@ __device__ __forceinline__ float wave_min16(const float (&h)[16], uint32_t lane,
 }
 
 // ---------------------------------------------------------------------------------
-// ITEM WALK (round 4): the subtree below a hand-off node as a wave-wide work list instead of 64 private depth-first walks.
-// The per-lane walk leaves most of the wave idle -- a visit runs with 19 of 64 lanes, a cell round with 13 -- because every
-// converged round lasts until its slowest lane has made its step, and a lane's steps are a dependent chain (rays that
-// skim the surface crawl from 2x2-cell node to node).  Here a unit of work is an ITEM (ray, node) or (ray, cell) on a
-// stack in the wave's LDS: the lanes that take the hand-off node push their children, and every round the wave pops up
-// to 64 items of ONE level from the top of the stack -- any lane takes any item: it pulls the ray's traversal constants
-// from the owning lane's registers (ds_bpermute, no copy of the ray in LDS), evaluates the node's record exactly as a
-// per-lane visit does (same shear_line / child_mask arithmetic), and pushes the children that pass (ballot + mbcnt
-// prefix per child slot); a cell item runs the two-triangle test and merges its hit into the ray's entry of an LDS table
-// with one 64-bit minimum -- key = (t bits, ~prim_index): the closest hit, the higher primitive on a tie, the order the
-// brute force produces (kdtree.h:2424-2448).  A crawling ray's chain is thereby spread over the idle lanes level by
-// level: the depth of the work list below a 16x16-cell node is four rounds whatever the slowest ray does.  What is lost
-// is front-to-back pruning between the children of one node (they are all pushed; t_hi only takes effect on the next
-// pop, after a cell round) -- harmless for the result (a minimum over a superset of the cells) and cheap while the
-// extra items ride in lanes that would have idled.
-// Stack discipline: items are pushed far child first, popped from the top; a round takes the run of equal-level items
-// on top (so a round is either all visits or all cell tests), at most 64, and fewer when the children it may push (four
-// per item) would not fit -- down to one item per round, which is a plain depth-first walk whose stack grows by at
-// most three per level, so HF_ITEM_CAP is never exceeded whatever the rays do.
-#ifndef HF_ITEM_WALK
-#define HF_ITEM_WALK 1
+// ITEM WALK (round 4): the subtrees below the beam sweep's hand-off nodes as a wave-wide work list instead of 64 private
+// depth-first walks.  The per-lane walk left most of the wave idle -- a visit ran with 19 of 64 lanes, a cell round with
+// 13 -- because every converged round lasts until its slowest lane has made its step, and a lane's steps are a
+// dependent chain (rays that skim the surface crawl from 2x2-cell node to node).  Here a unit of work is an ITEM,
+// (ray, node) or (ray, cell), on one of two stacks in the wave's LDS: the lanes that take a hand-off node push the
+// children they are to visit (ballot + mbcnt prefix per child slot), and every round the wave pops up to 64 node items
+// -- of any level: a visit is the same code at every level -- or up to 64 cell items.  Any lane takes any item: it
+// pulls the ray's traversal constants from the owning lane's registers (ds_bpermute, no copy of the ray in LDS),
+// evaluates the node's record exactly as a per-lane visit did (same shear_line / child_mask arithmetic) and pushes the
+// children that pass; a cell item runs the two-triangle test and merges its hit into the ray's entry of an LDS table
+// with one 64-bit minimum -- key = (t bits, ~prim_index): the closest hit, the higher primitive on a tie, what the
+// brute-force loop produces (kdtree.h:2424-2448).  A crawling ray's chain is thereby spread over the idle lanes, and
+// the hand-off nodes of a pass are worked off TOGETHER: items are pushed node after node and the list runs when it
+// holds a wave's worth (or the pass ends), so a node that only a handful of lanes take no longer costs a walk of its
+// own.  What is lost is front-to-back pruning between the children of a node and between the nodes of one run (t_hi
+// takes effect at the next pop, after a cell round) -- harmless for the result (a minimum over a superset of the
+// cells) and cheap while the extra items ride in lanes that would have idled.
+// Round selection: cell tests when a full round of them is waiting or no node item is left, visits otherwise (so the
+// cell stack never holds more than 63 + 4 x 64 items); a visit round takes fewer than 64 items when the children
+// they may push (four each) would not fit the node stack -- down to one item per round, a plain depth-first walk whose
+// stack grows by at most three per level -- so neither capacity is ever exceeded whatever the rays do.
+#define HF_NODE_CAP (HF_ITEM_FLUSH + 4 * 64 + 12 + 20) // a candidate of the sweep pushes up to 4 x 64 items onto fewer than HF_ITEM_FLUSH waiting
+                                                      // ones, and items_run needs 12 spare entries on top (one-item rounds grow the stack by up to 6)
+#define HF_CELL_CAP 320
+#ifndef HF_ITEM_FLUSH
+#define HF_ITEM_FLUSH 32 // the list runs when it holds this many node items (or the pass ends)
 #endif
-#define HF_ITEM_CAP 512
 struct hf_items_lds {
     unsigned long long best[64]; // per ray of the batch: (t bits << 32) | ~prim_index of its closest hit so far; all ones = none
     float2 uv[64];               // barycentrics of that hit
-    uint32_t stack[HF_ITEM_CAP]; // items: x | y << 4 (node / cell relative to the hand-off node, order space) | level << 8 | ray << 10
+    // items: x | y << 4 (node / cell relative to its hand-off node, order space) | level << 8 | ray << 10 | slot << 16
+    // (slot: the hand-off node's lane in the pass of the beam sweep)
+    uint32_t nodes[HF_NODE_CAP + HF_CELL_CAP]; // the node stack, then the cell stack
 };
 __device__ __forceinline__ float bperm_f(int src4, float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src4, __builtin_bit_cast(int, v)));
@@ -786,67 +811,99 @@ __device__ __forceinline__ float bperm_f(int src4, float v) {
 __device__ __forceinline__ uint32_t mbcnt64(uint64_t m) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, 0u));
 }
-// children (order-space mask m4) of the item's node -> items of level lv - 1, far child first; `on` lanes push
-__device__ __forceinline__ void push_children(hf_items_lds *q, uint32_t &count, bool on, uint32_t m4, uint32_t ray, uint32_t lvc,
-                                              uint32_t x2, uint32_t y2) {
-#pragma unroll
-    for (int k = 3; k >= 0; --k) {
-        const bool b = on && ((m4 >> k) & 1u) != 0u;
-        const uint64_t bm = __ballot(b);
-        if (b) q->stack[count + mbcnt64(bm)] = (x2 + (uint32_t) (k & 1)) | ((y2 + (uint32_t) (k >> 1)) << 4) | (lvc << 8) | (ray << 10);
-        count += (uint32_t) __builtin_popcountll(bm);
+__device__ __forceinline__ void items_clear(hf_items_lds *q, uint32_t lane) {
+    // (opaque: the pair of all-ones registers is otherwise hoisted out of the kernel's persistent loop and spilled)
+    uint32_t ones = 0xFFFFFFFFu;
+    asm volatile("" : "+v"(ones));
+    q->best[lane] = ((unsigned long long) ones << 32) | (unsigned long long) ones;
+}
+// the lane's own ray: closest hit of the item walks so far -> `best` (minimum t, higher prim on a tie)
+__device__ __forceinline__ void items_fold(hf_items_lds *q, uint32_t lane, hf_hit &best) {
+    __builtin_amdgcn_wave_barrier();
+    const unsigned long long mk = q->best[lane];
+    if (mk != ~0ull) {
+        const float2 uv = q->uv[lane];
+        best_update(best, __builtin_bit_cast(float, (uint32_t) (mk >> 32)), uv.x, uv.y, ~(uint32_t) mk);
     }
 }
-// All 64 lanes call this (wave-uniform control flow).  (nX, nY): order-space coordinates of the hand-off node (level
-// HF_SUBTREE_LEVEL), wave-uniform; cur0: this lane's order-space children of it to visit (0: the lane does not take the node).
+// wave-wide inclusive prefix sum (DPP: shifts within rows of 16, then the row totals broadcast into the rows above)
+__device__ __forceinline__ uint32_t wave_scan_add(uint32_t v) {
+    int x = (int) v;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, false); // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, false); // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, false); // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, false); // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false); // row_bcast:15 -> rows 1, 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false); // row_bcast:31 -> rows 2, 3
+    return (uint32_t) x;
+}
+// Every lane pushes the children (order-space mask m4; 0: none) of its node as items of level lvc, far child first:
+// onto the cell stack where cell_item, the node stack otherwise.  One prefix sum places everybody (node counts in the low
+// half word, cell counts in the high one): ballot-free, 4 predicated LDS writes.  tag = ray << 10 | slot << 16.
+__device__ __forceinline__ void push_children(hf_items_lds *q, uint32_t &nn, uint32_t &ncell, uint32_t m4, bool cell_item,
+                                              uint32_t tag, uint32_t lvc, uint32_t x2, uint32_t y2) {
+    const uint32_t c = (uint32_t) __builtin_popcount(m4);
+    const uint32_t cp = cell_item ? c << 16 : c;
+    const uint32_t inc = wave_scan_add(cp);
+    const uint32_t tot = (uint32_t) __builtin_amdgcn_readlane((int) inc, 63);
+    const uint32_t ex = inc - cp;
+    // (one array: the cell stack follows the node stack, see hf_items_lds)
+    uint32_t at = cell_item ? (uint32_t) HF_NODE_CAP + ncell + (ex >> 16) : nn + (ex & 0xFFFFu);
+    const uint32_t base = (lvc << 8) | tag;
+#pragma unroll
+    for (int k = 3; k >= 0; --k)
+        if ((m4 >> k) & 1u) q->nodes[at++] = (x2 + (uint32_t) (k & 1)) | ((y2 + (uint32_t) (k >> 1)) << 4) | base;
+    nn += tot & 0xFFFFu; ncell += tot >> 16;
+}
+// Works the node stack (nn items) off.  All 64 lanes call this (wave-uniform control flow).  The hand-off node of an
+// item is the node of lane `slot` of the current pass of the beam sweep: slab sb0 + slot / 4, cross coordinate nc of
+// that lane (xm: slabs run along x); fx, fy: the wave's mirror flags.
+static_assert(HF_ITEM_FLUSH - 1 + 4 * 64 <= HF_NODE_CAP - 12, "node stack: a candidate's children on top of the waiting items");
+static_assert(63 + 4 * 64 <= HF_CELL_CAP, "cell stack: a round of level-1 visits on top of less than a round of cells");
 template <bool ANY>
-__device__ __forceinline__ void walk_items(const hf_dev_field &f, const hf_ray_state &rs, float dxo, float dyo, bool fx, bool fy,
-                                           uint32_t nX, uint32_t nY, uint32_t cur0, float &thi, hf_items_lds *q, uint32_t lane) {
+__device__ __forceinline__ void items_run(const hf_dev_field &f, const hf_ray_state &rs, float dxo, float dyo, bool fx, bool fy,
+                                          bool xm, uint32_t sb0, uint32_t nc, uint32_t nn, float &thi, hf_items_lds *q, uint32_t lane) {
     const hf_trav &r = rs.r;
     const int top = f.top;
     const uint32_t fxm = fx ? ((1u << top) - 1u) : 0u, fym = fy ? ((1u << top) - 1u) : 0u;
-    uint32_t count = 0u; // items on the stack (wave-uniform)
-    push_children(q, count, cur0 != 0u, cur0, lane, (uint32_t) (HF_SUBTREE_LEVEL - 1), 0u, 0u);
-    while (count != 0u) { // wave-uniform
+    uint32_t nc_ = 0u; // cell items
+    while ((nn | nc_) != 0u) { // wave-uniform
         WCOUNT(3);
         __builtin_amdgcn_wave_barrier(); // (same wave: LDS operations stay in order; this keeps the compiler from reordering them)
-        // ---- the run of equal-level items on top of the stack ----
-        const bool has = lane < count;
-        const uint32_t it = has ? q->stack[count - 1u - lane] : 0xFFFFFFFFu;
-        const uint32_t lv = (uint32_t) __builtin_amdgcn_readfirstlane((int) ((it >> 8) & 3u));
-        const uint64_t diff = ~__ballot(has && ((it >> 8) & 3u) == lv);
-        uint32_t n = diff == 0ull ? 64u : (uint32_t) __builtin_ctzll(diff);
-        if (lv != 0u) { // room for four children per item (see above); always at least one item
-            const uint32_t room = (uint32_t) HF_ITEM_CAP - 12u - count; // count <= HF_ITEM_CAP - 3 always
-            const uint32_t fit = (int32_t) room > 0 ? room / 3u : 0u;
-            n = min(n, max(fit, 1u));
-        }
-        const bool mine = lane < n;
-        count -= n;
-        const uint32_t ray = mine ? (it >> 10) & 63u : lane;
-        const int src4 = (int) (ray << 2);
-        const uint32_t x = it & 15u, y = (it >> 4) & 15u;
-        if (lv != 0u) {
-            // ---- visits: node (X, Y) of level lv, for the ray of lane `ray` ----
+        if (nn != 0u && nc_ < 64u) {
+            // ---- a round of visits: up to 64 node items from the top of the node stack ----
+            uint32_t n = min(nn, 64u);
+            {   // room for the (at most three per popped item, net) node items the round may add
+                const int32_t room = (int32_t) HF_NODE_CAP - 12 - (int32_t) nn;
+                n = min(n, max(room > 0 ? (uint32_t) room / 3u : 0u, 1u));
+            }
+            const bool mine = lane < n;
+            const uint32_t it = mine ? q->nodes[nn - 1u - lane] : (lane << 10);
+            nn -= n;
+            const int src4 = (int) (((it >> 10) & 63u) << 2);
+            const uint32_t slot = (it >> 16) & 63u;
             hf_trav rr;
             rr.gxm = bperm_f(src4, r.gxm); rr.gxp = bperm_f(src4, r.gxp); rr.gym = bperm_f(src4, r.gym); rr.gyp = bperm_f(src4, r.gyp);
             rr.gz = bperm_f(src4, r.gz); rr.dz = bperm_f(src4, r.dz); rr.idx = bperm_f(src4, r.idx); rr.idy = bperm_f(src4, r.idy);
             rr.mz = bperm_f(src4, r.mz);
             const float rdxo = bperm_f(src4, dxo), rdyo = bperm_f(src4, dyo), rthi = bperm_f(src4, thi);
+            const uint32_t ck = (uint32_t) __builtin_amdgcn_ds_bpermute((int) (slot << 2), (int) nc), sk = sb0 + (slot >> 2);
             uint32_t m4 = 0u;
+            const uint32_t lv = (it >> 8) & 3u, x = it & 15u, y = (it >> 4) & 15u; // lv: 1 .. HF_SUBTREE_LEVEL - 1
             if (mine) {
-                const uint32_t X = (nX << ((uint32_t) HF_SUBTREE_LEVEL - lv)) + x, Y = (nY << ((uint32_t) HF_SUBTREE_LEVEL - lv)) + y;
+                const uint32_t X0 = xm ? sk : ck, Y0 = xm ? ck : sk;
+                const uint32_t X = (X0 << ((uint32_t) HF_SUBTREE_LEVEL - lv)) + x, Y = (Y0 << ((uint32_t) HF_SUBTREE_LEVEL - lv)) + y;
                 const float S = (float) (1u << lv), Sc = 0.5f * S;
-                // the item may predate a hit: its entry against the ray's current t_hi
+                // the item may predate a hit: its entry against the ray's current t_hi (any hit: a ray that has hit holds -1)
                 const float te = fmaxf(((float) X * S - rr.gxm) * rr.idx, ((float) Y * S - rr.gym) * rr.idy);
-                if (te <= rthi && (!ANY || rthi >= 0.f)) { // (any hit: a ray that has hit holds t_hi = -1)
+                if (te <= rthi && (!ANY || rthi >= 0.f)) {
                     WCOUNT(5); WLANES(7, 0); WHIST(11);
                     const uint32_t ix = X ^ (fxm >> lv), iy = Y ^ (fym >> lv);
                     const uint32_t k = (uint32_t) top - lv;
                     const float4 *rec = f.shear + (size_t) (hf_depth_off((int) k) - 1u + (iy << k) + ix) * 3;
-                    const float4 pl = rec[0], q01 = rec[1], q23 = rec[2];
+                    const float4 pl4 = rec[0], q01 = rec[1], q23 = rec[2]; // one round trip: the three parts are requested together
                     float gz, dz, mz;
-                    shear_line_v(rr, rdxo, rdyo, HF_LINE_EPS * (float) (1 << top), fx, fy, pl.x, pl.y, pl.z, pl.w,
+                    shear_line_v(rr, rdxo, rdyo, HF_LINE_EPS * (float) (1 << top), fx, fy, pl4.x, pl4.y, pl4.z, pl4.w,
                                  __builtin_fmaf((float) X, S, Sc), __builtin_fmaf((float) Y, S, Sc), gz, dz, mz);
                     hf_quad qd;
                     qd.lo[0] = q01.x; qd.hi[0] = q01.y; qd.lo[1] = q01.z; qd.hi[1] = q01.w;
@@ -854,19 +911,30 @@ __device__ __forceinline__ void walk_items(const hf_dev_field &f, const hf_ray_s
                     m4 = to_order(child_mask(rr, fx, fy, (float) X * S, (float) Y * S, Sc, qd, gz, dz, mz, rthi), fx, fy);
                 }
             }
-            push_children(q, count, mine, m4, ray, lv - 1u, 2u * x, 2u * y);
+            const uint32_t tag = it & 0x3FFC00u; // ray and slot
+            push_children(q, nn, nc_, m4, lv == 1u, tag, lv - 1u, 2u * x, 2u * y); // (m4 = 0 in the lanes without an item)
+            TSTAMP(4); // visit rounds
         } else {
-            // ---- cell tests: cell (x, y) of the hand-off node, for the ray of lane `ray` ----
+            // ---- a round of cell tests: up to 64 cell items from the top of the cell stack ----
+            const uint32_t n = min(nc_, 64u);
+            const bool mine = lane < n;
+            const uint32_t it = mine ? q->nodes[(uint32_t) HF_NODE_CAP + nc_ - 1u - lane] : (lane << 10);
+            nc_ -= n;
+            const uint32_t ray = (it >> 10) & 63u, slot = (it >> 16) & 63u;
+            const int src4 = (int) (ray << 2);
             const v3 oo = mk3(bperm_f(src4, rs.oo.x), bperm_f(src4, rs.oo.y), bperm_f(src4, rs.oo.z));
             const v3 od = mk3(bperm_f(src4, rs.od.x), bperm_f(src4, rs.od.y), bperm_f(src4, rs.od.z));
             const float rmaxt = bperm_f(src4, rs.maxt);
             const float rthi = ANY ? bperm_f(src4, thi) : 0.f;
+            const uint32_t ck = (uint32_t) __builtin_amdgcn_ds_bpermute((int) (slot << 2), (int) nc), sk = sb0 + (slot >> 2);
             hf_hit b;
             b.hit = false; b.t = __builtin_inff(); b.u = 0.f; b.v = 0.f; b.prim = 0u;
             unsigned long long key = ~0ull;
             if (mine && (!ANY || rthi >= 0.f)) {
                 WCOUNT(6); WLANES(7, 16); WHIST(8);
-                const int cxx = (int) (((nX << HF_SUBTREE_LEVEL) + x) ^ fxm), cyy = (int) (((nY << HF_SUBTREE_LEVEL) + y) ^ fym);
+                const uint32_t X0 = xm ? sk : ck, Y0 = xm ? ck : sk, x = it & 15u, y = (it >> 4) & 15u;
+                const int cxx = (int) (((X0 << HF_SUBTREE_LEVEL) + x) ^ fxm), cyy = (int) (((Y0 << HF_SUBTREE_LEVEL) + y) ^ fym);
+                // (32-bit byte offsets from the uniform base: hf_create limits the grid to 2^30 vertices)
                 const uint32_t off = ((uint32_t) cyy * (uint32_t) f.W + (uint32_t) cxx) << 2, pitch = (uint32_t) f.W << 2;
                 const char *hb = (const char *) f.h;
                 const float z00 = *(const float *) (hb + off) * f.s, z10 = *(const float *) (hb + off + 4u) * f.s;
@@ -886,6 +954,7 @@ __device__ __forceinline__ void walk_items(const hf_dev_field &f, const hf_ray_s
                 tb = tb + __builtin_fabsf(tb) * 1e-6f + 1e-30f;
                 thi = ANY ? -1.f : fminf(thi, tb);
             }
+            TSTAMP(5); // cell rounds
         }
     }
 }
@@ -912,7 +981,8 @@ __device__ __forceinline__ void walk_items(const hf_dev_field &f, const hf_ray_s
 // coordinate only grows.
 #define HF_BEAM_CAND (4 * HF_BEAM_ROWS)
 struct hf_beam_lds {
-    struct { float4 box, pl, q01, q23; } e[HF_BEAM_CAND]; // (min z, max z) and record of the pass's nodes
+    struct { float4 pl, q01, q23; } e[HF_BEAM_CAND]; // record of the pass's nodes ...
+    float2 box[HF_BEAM_CAND];                          // ... and their (min z, max z)
     float hdr[20];               // the beam (wave-uniform), parked here between passes instead of in registers; [16] = largest xy margin
 };
 enum { BM_ISN, BM_ISX, BM_ICN, BM_ICX, BM_AS, BM_BS, BM_AC, BM_BC, BM_GCLO, BM_GCHI, BM_DCN, BM_DCX, BM_ZLO, BM_ZHI, BM_DZN, BM_DZX };
@@ -921,7 +991,7 @@ enum { BM_ISN, BM_ISX, BM_ICN, BM_ICX, BM_AS, BM_BS, BM_AC, BM_BC, BM_GCLO, BM_G
 // root with the t_hi and the best hit reached so far (re-testing a cell is harmless: the result is a minimum).
 template <bool ANY>
 __device__ __forceinline__ bool walk_beam_impl(const hf_dev_field &f, const hf_ray_state &rs, bool alive, bool fx, bool fy,
-                                               hf_hit &best, float &thi, hf_beam_lds *lds, hf_items_lds *items) {
+                                               float &thi, hf_beam_lds *lds, hf_items_lds *items) {
     const hf_trav &r = rs.r;
     // (opaque copies: everything derived from the lane number or the level count is loop-invariant for the kernel's
     // persistent loop, and the compiler would compute it all at kernel entry and then spill it -- 30 registers)
@@ -965,9 +1035,7 @@ __device__ __forceinline__ bool walk_beam_impl(const hf_dev_field &f, const hf_r
         smin = wave_min_u32(alive ? (uint32_t) fminf(fmaxf(sa * iS, 0.f), lim) : 0xFFFFFFFFu);
         smax = wave_max_u32(alive ? (uint32_t) fminf(fmaxf(sb2 * iS, 0.f), lim) : 0u);
     }
-    hf_src_global src;
-    src.mip = f.mip; src.shear = f.shear; src.h = f.h; src.top = f.top; src.W = f.W;
-    const uint32_t lfxm = rs.fx ? ((1u << top) - 1u) : 0u, lfym = rs.fy ? ((1u << top) - 1u) : 0u;
+    TSTAMP(1); // beam set-up: sixteen wave-wide extrema, slab range
     for (uint32_t sb0 = smin; sb0 <= smax; sb0 += HF_BEAM_ROWS) { // wave-uniform
         WCOUNT(0);
         __builtin_amdgcn_wave_barrier();
@@ -1006,12 +1074,13 @@ __device__ __forceinline__ bool walk_beam_impl(const hf_dev_field &f, const hf_r
                 const float zs = __builtin_fmaf(2.f * lds->hdr[16], box.y - box.x, 1e-5f * (__builtin_fabsf(za) + __builtin_fabsf(zb)) + 1e-30f);
                 cand = (u0 <= u1) & (za - zs <= box.y) & (zb + zs >= box.x);
                 if (cand) {
-                    lds->e[lane].box = make_float4(box.x, box.y, 0.f, 0.f);
+                    lds->box[lane] = box;
                     lds->e[lane].pl = pl; lds->e[lane].q01 = q01; lds->e[lane].q23 = q23;
                 }
             }
         }
         uint64_t cm = __ballot(cand);
+        TSTAMP(2); // a pass: node assignment, box + record loads, beam test, LDS table
         __builtin_amdgcn_wave_barrier(); // the table is read below by every lane (same wave: LDS operations stay in order)
         // One loop with ONE walk site at its end: a lane that takes a node notes it (node + children packed in one
         // register: hf_create allows at most 2^11 nodes per side at this level) and the walk below runs at once.  The
@@ -1020,92 +1089,57 @@ __device__ __forceinline__ bool walk_beam_impl(const hf_dev_field &f, const hf_r
         // of a pass and walking them together when a holder wants a second one was measured too: a lane that will hit in
         // its node still passes the box and record tests of the nodes behind it, so nearly every node flushes -- 2.1
         // instead of 2.2 walks, 9.2 instead of 6.8 box tests, 2.80 ms.
-        uint32_t held = 0u;
+        // The candidates front to back: box test and record per lane, the children a lane is to visit go onto the wave's
+        // work list; the list runs (items_run) when it holds a wave's worth of items or the pass ends.  (Until round 4 a
+        // node was walked at once by the lanes that took it, each lane on its own: 2.2 walks per batch with half of the
+        // lanes in each, every one as long as its slowest lane.)
+        uint32_t nn = 0u; // node items waiting
         bool done = false;
-        while (true) { // wave-uniform
-            if (cm != 0ull) {
-                const uint32_t k = (uint32_t) __builtin_ctzll(cm);
-                WCOUNT(1);
-                const uint32_t ck = (uint32_t) __builtin_amdgcn_readlane((int) nc, (int) k), sk = sb0 + (k >> 2);
-                const uint32_t ci = xm ? sk : ck, nodej = xm ? ck : sk;
-                const float4 cbox = lds->e[k].box; // uniform address: broadcast
-                // ---- per-lane test of the node's box with the row sweep's arithmetic ----
-                const float fXc = (float) ci * S, fYc = (float) nodej * S;
-                const float xlo = (fXc - r.gxm) * r.idx, xhi = (fXc + S - r.gxp) * r.idx;
-                const float ylo = (fYc - r.gym) * r.idy, yhi = (fYc + S - r.gyp) * r.idy;
-                const float u0 = fmaxf(fmaxf(xlo, ylo), 0.f), u1 = fminf(fminf(xhi, yhi), thi);
-                const float za = __builtin_fmaf(u0, r.dz, r.gz), zb = __builtin_fmaf(u1, r.dz, r.gz);
-                const float bz = __builtin_fmaf(2.f * rs.m, cbox.y - cbox.x, r.mz); // needle term: 2 m x (range), see hf_shear_kernel
-                const bool mine = (u0 <= u1) & (fminf(za, zb) - bz <= cbox.y) & (fmaxf(za, zb) + bz >= cbox.x);
-                if (__ballot(mine) == 0ull) {
-                    // nobody overlaps this node; done when nobody can reach its slab -- or any later one -- before its t_hi
-                    const float tsk = ((float) sk * S - (xm ? r.gxm : r.gym)) * (xm ? r.idx : r.idy);
-                    cm &= cm - 1ull;
-                    if (__ballot(tsk <= thi) == 0ull) { done = true; cm = 0ull; }
-                    continue;
-                }
+        while (cm != 0ull) { // wave-uniform
+            const uint32_t k = (uint32_t) __builtin_ctzll(cm);
+            WCOUNT(1);
+            const uint32_t ck = (uint32_t) __builtin_amdgcn_readlane((int) nc, (int) k), sk = sb0 + (k >> 2);
+            const uint32_t ci = xm ? sk : ck, nodej = xm ? ck : sk;
+            const float2 cbox = lds->box[k]; // uniform address: broadcast
+            // ---- per-lane test of the node's box with the row sweep's arithmetic ----
+            const float fXc = (float) ci * S, fYc = (float) nodej * S;
+            const float xlo = (fXc - r.gxm) * r.idx, xhi = (fXc + S - r.gxp) * r.idx;
+            const float ylo = (fYc - r.gym) * r.idy, yhi = (fYc + S - r.gyp) * r.idy;
+            const float u0 = fmaxf(fmaxf(xlo, ylo), 0.f), u1 = fminf(fminf(xhi, yhi), thi);
+            const float za = __builtin_fmaf(u0, r.dz, r.gz), zb = __builtin_fmaf(u1, r.dz, r.gz);
+            const float bz = __builtin_fmaf(2.f * rs.m, cbox.y - cbox.x, r.mz); // needle term: 2 m x (range), see hf_shear_kernel
+            const bool mine = (u0 <= u1) & (fminf(za, zb) - bz <= cbox.y) & (fmaxf(za, zb) + bz >= cbox.x);
+            cm &= cm - 1ull;
+            if (__ballot(mine) == 0ull) {
+                // nobody overlaps this node; done when nobody can reach its slab -- or any later one -- before its t_hi
+                // (a t_hi that waiting items have yet to shorten only delays this)
+                const float tsk = ((float) sk * S - (xm ? r.gxm : r.gym)) * (xm ? r.idx : r.idy);
+                if (__ballot(tsk <= thi) == 0ull) { done = true; cm = 0ull; }
+            } else {
                 WCOUNT(2);
-                // the node's own record, for all lanes at once
-                uint32_t cur0 = 0u;
+                // the node's own record, for all lanes at once (the first visit of the hand-off, hoisted)
+                const float4 pl = lds->e[k].pl, q01 = lds->e[k].q01, q23 = lds->e[k].q23;
+                const float Sc = 0.5f * S;
+                float gz, dz, mz;
+                shear_line_v(r, dxo, dyo, HF_LINE_EPS * (float) (1 << top), fx, fy, pl.x, pl.y, pl.z, pl.w, fXc + Sc, fYc + Sc, gz, dz, mz);
+                hf_quad q;
+                q.lo[0] = q01.x; q.hi[0] = q01.y; q.lo[1] = q01.z; q.hi[1] = q01.w;
+                q.lo[2] = q23.x; q.hi[2] = q23.y; q.lo[3] = q23.z; q.hi[3] = q23.w;
+                const uint32_t m4 = child_mask(r, fx, fy, fXc, fYc, Sc, q, gz, dz, mz, thi);
+                const uint32_t cur0 = mine ? to_order(m4, fx, fy) : 0u;
+                if (__ballot(cur0 != 0u) != 0ull) WCOUNT(4);
                 {
-                    const float4 pl = lds->e[k].pl, q01 = lds->e[k].q01, q23 = lds->e[k].q23;
-                    const float Sc = 0.5f * S;
-                    float gz, dz, mz;
-                    shear_line(f, rs, fx, fy, pl.x, pl.y, pl.z, pl.w, fXc + Sc, fYc + Sc, gz, dz, mz);
-                    hf_quad q;
-                    q.lo[0] = q01.x; q.hi[0] = q01.y; q.lo[1] = q01.z; q.hi[1] = q01.w;
-                    q.lo[2] = q23.x; q.hi[2] = q23.y; q.lo[3] = q23.z; q.hi[3] = q23.w;
-                    const uint32_t m4 = child_mask(r, fx, fy, fXc, fYc, Sc, q, gz, dz, mz, thi);
-                    cur0 = mine ? to_order(m4, fx, fy) : 0u;
+                    uint32_t no_cells = 0u;
+                    push_children(items, nn, no_cells, cur0, false, (lane << 10) | (k << 16), (uint32_t) (HF_SUBTREE_LEVEL - 1), 0u, 0u);
                 }
-                cm &= cm - 1ull;
-                if (__ballot(cur0 != 0u) == 0ull) continue;
-                held = cur0 != 0u ? ci | (nodej << 12) | (cur0 << 24) : 0u; // walked at once, below
             }
-            // ---- walk the node just taken ----
-            if (__ballot(held != 0u) != 0ull) {
-                WCOUNT(4);
-#if defined(HF_WSTATS) && HF_WSTATS == 3
-                {   // participants of this hand-off, and how many of them took part in an earlier hand-off of the batch
-                    const uint64_t pm = __ballot(held != 0u);
-                    uint32_t *c = wcnt_base();
-                    const uint64_t prev = (uint64_t) c[11] | ((uint64_t) c[12] << 32);
-                    __builtin_amdgcn_wave_barrier();
-                    if (lane == (uint32_t) __builtin_ctzll(pm)) {
-                        c[8] += (uint32_t) __builtin_popcountll(pm); c[9] += (uint32_t) __builtin_popcountll(pm & prev);
-                        const uint64_t nu = prev | pm; c[11] = (uint32_t) nu; c[12] = (uint32_t) (nu >> 32);
-                    }
-                }
-#endif
-#if defined(HF_WSTATS) && HF_WSTATS == 2
-                uint32_t pre_v, pre_c; bool tail;
-                {   // lanes that can still reach the node's slab: the batch's unfinished lanes
-                    const uint32_t sk = xm ? (held & 0xFFFu) : ((held >> 12) & 0xFFFu);
-                    const uint32_t sku = (uint32_t) __builtin_amdgcn_readfirstlane((int) sk);
-                    const float tsk = ((float) sku * S - (xm ? r.gxm : r.gym)) * (xm ? r.idx : r.idy);
-                    tail = __builtin_popcountll(__ballot(alive && tsk <= thi)) < HF_WSTATS_THR;
-                    pre_v = wcnt_base()[5]; pre_c = wcnt_base()[6];
-                }
-#endif
-#if HF_ITEM_WALK
-                {   // the node as a wave-wide work list (walk_items): every lane takes part, the holders push their children
-                    const uint32_t hn = (uint32_t) __builtin_amdgcn_readlane((int) held, __builtin_ctzll(__ballot(held != 0u)));
-                    walk_items<ANY>(f, rs, dxo, dyo, fx, fy, hn & 0xFFFu, (hn >> 12) & 0xFFFu, held >> 24, thi, items, lane);
-                }
-#else
-                if (held != 0u) {
-                    const bool h = walk_subtree_from<ANY>(f, src, rs, r, rs.fx, rs.fy, lfxm, lfym, held & 0xFFFu, (held >> 12) & 0xFFFu,
-                                                          HF_SUBTREE_LEVEL, held >> 24, thi, best);
-                    if (ANY && h) thi = -1.f;
-                }
-#endif
-#if defined(HF_WSTATS) && HF_WSTATS == 2
-                if (tail && lane == 0u) { uint32_t *c = wcnt_base(); c[8] += c[5] - pre_v; c[9] += c[6] - pre_c; c[10]++; }
-#endif
-                held = 0u;
+            // ---- the work list: when it holds a wave's worth, and before the pass ends ----
+            if (nn >= (uint32_t) HF_ITEM_FLUSH || (cm == 0ull && nn != 0u)) {
+                TSTAMP(3); // candidates: per-lane box tests, hoisted records, pushes
+                items_run<ANY>(f, rs, dxo, dyo, fx, fy, xm, sb0, nc, nn, thi, items, lane);
+                nn = 0u;
                 if (ANY && __ballot(thi >= 0.f) == 0ull) return true;
             }
-            if (cm == 0ull) break;
         }
         if (done) return true;
         // done when nobody can reach the first slab of the next pass before its t_hi
@@ -1120,23 +1154,10 @@ __device__ __forceinline__ bool walk_beam_impl(const hf_dev_field &f, const hf_r
 template <bool ANY>
 __device__ __forceinline__ bool walk_beam(const hf_dev_field &f, const hf_ray_state &rs, bool alive, bool fx, bool fy,
                                           hf_hit &best, float &thi, hf_beam_lds *lds, hf_items_lds *items) {
-#if HF_ITEM_WALK
     const uint32_t lane = threadIdx.x & 63u;
-    {   // (opaque: the pair of all-ones registers is otherwise hoisted out of the kernel's persistent loop and spilled)
-        uint32_t ones = 0xFFFFFFFFu;
-        asm volatile("" : "+v"(ones));
-        items->best[lane] = ((unsigned long long) ones << 32) | (unsigned long long) ones;
-    }
-#endif
-    const bool done = walk_beam_impl<ANY>(f, rs, alive, fx, fy, best, thi, lds, items);
-#if HF_ITEM_WALK
-    __builtin_amdgcn_wave_barrier();
-    const unsigned long long mk = items->best[lane];
-    if (mk != ~0ull) {
-        const float2 uv = items->uv[lane];
-        best_update(best, __builtin_bit_cast(float, (uint32_t) (mk >> 32)), uv.x, uv.y, ~(uint32_t) mk);
-    }
-#endif
+    items_clear(items, lane);
+    const bool done = walk_beam_impl<ANY>(f, rs, alive, fx, fy, thi, lds, items);
+    items_fold(items, lane, best);
     return done;
 }
 
@@ -1385,9 +1406,7 @@ __global__ __launch_bounds__(HF_BLOCK, (MODE == 2 ? HF_TRACE_WAVES_FUSED : HF_TR
             best.hit = false; best.t = __builtin_inff(); best.u = 0.f; best.v = 0.f; best.prim = 0u;
             const uint8_t *active = ka->active;
             const bool act = valid && (active ? ((active + ub)[lo] != 0) : true);
-#ifdef HF_TSTATS
-            const long long tb0 = clock64();
-#endif
+            TSTART();
             hf_ray_state rs = {}; // fully defined on every path: undefined fields become loop-carried registers
             bool alive;
             {
@@ -1409,9 +1428,7 @@ __global__ __launch_bounds__(HF_BLOCK, (MODE == 2 ? HF_TRACE_WAVES_FUSED : HF_TR
                                   (__builtin_fabsf(ux * uy0 - uy * ux0) <= HF_COH_DIR * __builtin_fabsf(ux * uy0));
                 const bool coherent = __ballot(alive && !near) == 0ull;
                 // incoherent wave: the shared walk degenerates to handing the root to every live lane
-#ifdef HF_TSTATS
-                const long long tb1 = clock64();
-#endif
+                TSTAMP(0); // ray set-up, clip and coherence test
                 // (one root-walk site for both the incoherent wave and a coherent wave whose beam sweep gives up)
                 float thi = alive ? rs.thi : -1.f; // dead lanes overlap nothing
                 bool root = alive;
@@ -1425,10 +1442,11 @@ __global__ __launch_bounds__(HF_BLOCK, (MODE == 2 ? HF_TRACE_WAVES_FUSED : HF_TR
                     (void) walk_subtree<MODE == 1>(f, src, rs, rs.r, rs.fx, rs.fy, lfxm, lfym, 0u, 0u, f.top, thi, best);
                 }
                 if (coherent && f.top > HF_SUBTREE_LEVEL) WSTATS_EXPORT(alive, best);
-#ifdef HF_TSTATS
-                if (alive) { best.t = (float) (clock64() - tb0); best.v = (float) (tb1 - tb0); }
-#endif
+                TSTAMP(7); // fold of the item walks' hit table (and whatever the stamps above do not cover)
             }
+#ifdef HF_TSTATS
+            TSTATS_EXPORT(am != 0ull, valid, best);
+#endif
             asm volatile("" : "+s"(ka)); // the ~30 output pointers: loaded here, not before the walk
             // Request the next batch's rays BEFORE this batch's records are stored: vector-memory operations
             // complete in order, so a wave that loads after its stores waits for the store acknowledgements

@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Per-batch cycle breakdown from an -DHF_TSTATS build (diagnostic): total, setup, per-lane subtree walk."""
+"""Per-batch cycle breakdown of the traversal kernel from an -DHF_TSTATS build (HF_LIB selects it): shader cycles per
+phase of a traversing batch of the bench wavefront, stamped by lane 0 of every wave (TSTAMP in csrc/hf_kernels.hip).
+usage: HF_LIB=scratch_so/libhf_X_ts.so scripts/tstats.py grid film spp [fused]   (fused: the fused launch, RayFlags.All)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, hf_amd
@@ -9,24 +11,18 @@ grid, film, spp = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 dev = torch.device("cuda", 0)
 shape = hf_amd.Heightfield(heightfield=hf_amd.workload.sine_heights(grid, grid, device=dev), max_height=0.5)
 rays = hf_amd.workload.ortho_rays(film, film, spp, dev)
-pi = shape.ray_intersect_preliminary(hf_amd.Ray3f(rays[0:3], rays[3:6], rays[6]))
-trav = (pi.t != float("inf")).reshape(-1, 64)
-z = torch.zeros(1, device=dev, dtype=torch.float64)
-def mx(x): return torch.where(trav, x.double().reshape(-1, 64), z).max(1).values
-tot, sub, setup = mx(pi.t), mx(pi.prim_uv[0]), mx(pi.prim_uv[1])
-w = trav.any(1)
-print(f"batches {int(w.sum())}: cycles/batch total {float(tot[w].mean()):.0f}, setup+coherence {float(setup[w].mean()):.0f}, "
-      f"subtree walks {float(sub[w].mean()):.0f}, shared walk {float((tot - sub - setup)[w].mean()):.0f}")
-tt = tot[w]
-q = torch.quantile(tt[torch.randperm(tt.numel(), device=tt.device)[:1000000]], torch.tensor([0.1, 0.25, 0.5, 0.75, 0.9, 0.99], dtype=torch.float64, device=tt.device))
-print("total cycles/batch quantiles 10/25/50/75/90/99 %:", [int(x) for x in q.tolist()])
-srt = torch.sort(tt, descending=True).values
-cs = torch.cumsum(srt, 0) / srt.sum()
-for frac in (0.01, 0.05, 0.1, 0.25, 0.5):
-    k = int(frac * srt.numel())
-    print(f"  the most expensive {100 * frac:.0f} % of the batches take {100 * float(cs[k]):.1f} % of the cycles")
-hits = trav.sum(1)[w].double()
-for lo, hi in ((1, 16), (16, 48), (48, 64), (64, 65)):
-    m = (hits >= lo) & (hits < hi)
-    if m.any():
-        print(f"  batches with {lo}..{hi - 1} hit lanes: {100 * float(m.double().mean()):.1f} % of batches, mean cycles {float(tt[m].mean()):.0f}")
+ray = hf_amd.Ray3f(rays[0:3], rays[3:6], rays[6])
+pi = shape.ray_intersect(ray, hf_amd.RayFlags.All) if len(sys.argv) > 4 and sys.argv[4] == "fused" else shape.ray_intersect_preliminary(ray)
+t = pi.t.reshape(-1, 64).double()
+lane = (pi.prim_index.reshape(-1, 64).to(torch.int64) & 0xFFFFFFFF)
+trav = (torch.isfinite(t[:, 0]) & (lane[:, 1] == 1) & (lane[:, 63] == 63))   # batches that exported (any lane alive)
+c = t[trav][:, :16]
+names = ["set-up, clip, coherence", "beam set-up", "passes (node loads, beam test)", "candidates (box, record, push)", "visit rounds", "cell rounds",
+         "-", "rest of the traversal + fold", "output of the previous batch (stores, SI)"]
+c[:, 8] = torch.where(c[:, 8] > 1e6, torch.full_like(c[:, 8], float("nan")), c[:, 8])   # a wave's first batch: no previous one
+c[:, 8] = torch.nan_to_num(c[:, 8], nan=float(torch.nanmean(c[:, 8])))
+tot = float(c[:, :9].sum(1).mean())
+print(f"batches {int(trav.sum())}: {tot:.0f} cycles per batch (stamped; the stamps cost ~10 %)")
+for k, nm in enumerate(names):
+    if nm != "-":
+        print(f"  {nm:45s} {float(c[:, k].mean()):8.0f}  {100 * float(c[:, k].mean()) / tot:5.1f} %")
