@@ -76,6 +76,25 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    collective = None
+    if world > 1:
+        # what the collective saw, as the process group itself reports it: every rank's (host, device index, device name,
+        # PCI bus id) gathered on rank 0 -- under nccl (= RCCL) the ranks must hold DISTINCT devices
+        import socket
+        props = torch.cuda.get_device_properties(local)
+        mine = {"rank": rank, "host": socket.gethostname(), "device": local, "name": props.name,
+                "pci_bus_id": getattr(props, "pci_bus_id", None), "uuid": str(getattr(props, "uuid", ""))}
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        if backend == "nccl":
+            ids = [(g["host"], g["device"]) for g in gathered]
+            assert len(set(ids)) == world, f"ranks share a device under nccl: {ids}"
+        try:
+            nccl_version = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:
+            nccl_version = None
+        collective = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "rccl_version": nccl_version,
+                      "ranks": gathered, "hip": torch.version.hip, "torch": torch.__version__}
 
     N, Wf, spp = args.grid, args.film, args.spp
     R_total = Wf * Wf * spp
@@ -190,6 +209,14 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    # the band kept accumulating during the timed steps: a launch that touched a row outside [rows[0], rows[1]) would
+    # have had that row left out of the all-reduce -- check instead of assuming (static scene: must hold)
+    chk = band.to(torch.int64).clone()
+    if world > 1:
+        lo_c, hi_c = chk[0:1].clone(), chk[1:2].clone()
+        dist.all_reduce(lo_c, op=dist.ReduceOp.MIN); dist.all_reduce(hi_c, op=dist.ReduceOp.MAX)
+        chk = torch.cat([lo_c, hi_c])
+    assert int(chk[0]) >= rows[0] and int(chk[1]) <= rows[1], f"gradient rows {chk.tolist()} outside the all-reduced band {rows}"
     ms_step = 1e3 * elapsed / args.steps
     grad_h = grads[(step_no[0] - 1) % len(grads)]
     grad_sample = grad_h.clone()          # the reduced gradient of the last timed step (checksums below)
@@ -280,9 +307,12 @@ def main():
                                           if strong else f"one wavefront per rank ({world}); ") +
                                          "heights replicated, 1 async all-reduce of the gradient texture per step"},
                "allreduce": {"rows": [rows[0], rows[1]], "bytes": (rows[1] - rows[0]) * N * 4,
-                             "overlap": "with the next step's kernels (headline)",
+                             "overlap": "with the next step's kernels (headline); serial_* = the all-reduce waited for inside "
+                                        "the step: the number an optimiser that consumes the gradient before the next forward sees",
                              "serial_ms_per_step": None if serial_ms is None else round(serial_ms, 4),
                              "serial_value": None if serial_ms is None else round(total_rays / (serial_ms * 1e-3) / 1e6, 2)},
+               "collective": collective,
+               "library": library_id(_capi),
                "grad_l2": gnorm, "grad_checksum": gsum,
                "roofline": roofline, "cpu_baseline": cpu, "other_launches_ms": extras}
         print(json.dumps(out), flush=True)
@@ -290,6 +320,15 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     return out
+
+
+def library_id(_capi):
+    """which libhf.so the numbers come from (HF_LIB can point the package at an A/B build: the line says so)"""
+    import hashlib
+    path = os.environ.get("HF_LIB") or _capi._build.LIB_PATH
+    return {"path": os.path.relpath(path, ROOT) if path.startswith(ROOT) else path,
+            "sha256_16": hashlib.sha256(open(path, "rb").read()).hexdigest()[:16],
+            "hf_lib_override": bool(os.environ.get("HF_LIB"))}
 
 
 def _rows_of(buf, n):
@@ -397,12 +436,21 @@ def other_launches(torch, hf_amd, _capi, lib, shape, rays, r_s, pi_s, si_s, si, 
                "loss_first": round(hist[0], 6), "loss_last": round(hist[-1], 6),
                "centred_height_error_first": round(inverse_heights.run.start_centred_error, 5),
                "centred_height_error_last": round(inverse_heights.run.last_centred_error, 5)}
-        # (b) wall-clock of the same loop at configs[1]'s size (timing only)
+        # (b) the same loop at configs[1]'s size (timing only): the eager autograd loop, and ONE step captured into a HIP
+        #     graph and replayed 100 times (inverse_heights.run_captured: no host work per step; hf_adam_step_scheduled)
         hist, err, wall = inverse_heights.run(grid=1024, film=512, spp=16, steps=100, lr=0.005, verbose=False)
+        hist_c, err_c, tm = inverse_heights.run_captured(grid=1024, film=512, spp=16, steps=100, lr=0.005)
         out["configs4_inverse_loop"] = {"recovery": rec,
                                         "timing": {"grid": 1024, "rays_per_step": 512 * 512 * 16, "adam_steps": 100,
-                                                   "wall_clock_s": round(wall, 4), "loss_first": round(hist[0], 6),
-                                                   "loss_last": round(hist[-1], 6)}}
+                                                   "wall_clock_s": round(tm["wall_clock_s"], 4),
+                                                   "ms_per_step": round(tm["wall_ms_per_step"], 4),
+                                                   "kernel_ms_sum_per_step": round(tm["gpu_ms_per_step"], 4),
+                                                   "host_overhead_ms_per_step": round(max(0.0, tm["wall_ms_per_step"] - tm["gpu_ms_per_step"]), 4),
+                                                   "how": "one optimisation step captured into a HIP graph, replayed 100 times",
+                                                   "loss_first": round(hist_c[0], 6), "loss_last": round(hist_c[-1], 6),
+                                                   "eager_autograd_loop": {"wall_clock_s": round(wall, 4), "ms_per_step": round(10.0 * wall, 4),
+                                                                           "host_overhead_ms_per_step": round(max(0.0, 10.0 * wall - tm["gpu_ms_per_step"]), 4),
+                                                                           "loss_first": round(hist[0], 6), "loss_last": round(hist[-1], 6)}}}
     except Exception as e:   # the headline number must not depend on the example
         out["configs4_inverse_loop"] = {"error": repr(e)}
     return out

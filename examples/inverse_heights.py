@@ -124,6 +124,8 @@ def run(grid=128, film=256, spp=1, steps=100, lr=0.02, device="cuda", verbose=Tr
             both = valid & tgt_valid
             # the multi-light renders only (configs[4]); mean over the pixels of the WHOLE film: shard losses add up
             loss = ((images - tgt_img) ** 2).sum() / npix_total
+            # (the depth term is normalised per FILM sample -- npix_total * spp -- since round 3, so that the shards'
+            # terms add up; rounds 1-2 divided by the number of valid samples: the same --depth-weight weighs less now)
             if depth_weight > 0:                                    # optional extra supervision, off by default
                 loss = loss + depth_weight * (((depth - tgt_depth) ** 2) * both).sum() / (npix_total * spp)
             loss.backward()
@@ -153,6 +155,102 @@ def run(grid=128, film=256, spp=1, steps=100, lr=0.02, device="cuda", verbose=Tr
     return hist, err, wall
 
 
+def run_captured(grid=128, film=256, spp=1, steps=100, lr=0.02, device="cuda", seed=0, record=None):
+    """The image-loss loop of run() (box film, no shadows, attached geometry) with ONE optimisation step captured into a
+    HIP graph and replayed `steps` times: trace -> direct lighting -> loss and its image gradient -> lighting adjoint ->
+    hf_adjoint -> hf_adam_step_scheduled (update + rebuild).  No autograd, no allocation, no host work per step: the
+    step sizes of all steps sit in a device table (hf_adam_lr_t: hf_adam_step's own arithmetic), a device counter picks
+    the entry, the losses go to a device array.  Same kernels on the same inputs as run(): the trajectories agree to
+    the order of the float atomics (tests/test_gpu_inverse_loop.py).
+    Returns (loss history, mean |h - h*|, timing): timing = wall-clock of the replays, HIP-event time of the replays
+    (the kernels of a step back to back), and both per step."""
+    import ctypes as C
+    from hf_amd import _capi
+    from hf_amd.shape import _DIFF_ROWS, _fill, _rows
+    dev = torch.device(device)
+    lib = _capi.lib()
+    lights = torch.cat([LIGHTS / LIGHTS.norm(dim=1, keepdim=True), torch.full((len(LIGHTS), 1), math.pi)], 1)
+    K = lights.shape[0]
+    target_h = hf_amd.workload.sine_heights(grid, grid, device=dev)
+    target = hf_amd.Heightfield(heightfield=target_h, max_height=0.5)
+    rays = hf_amd.workload.ortho_rays(film, film, spp, dev, seed=seed, origin=(0.6, 0.35, 2.0),
+                                      target=(0.0, 0.0, 0.25), scale=(0.95, 0.95, 1.0))
+    ray = hf_amd.Ray3f(rays[0:3], rays[3:6], rays[6])
+    with torch.no_grad():
+        tgt_img, _, _ = render(target, ray, lights, spp)
+    tgt_img = tgt_img.contiguous()
+    R, npix = rays.shape[1], film * film
+    shape = hf_amd.Heightfield(heightfield=torch.full_like(target_h, 0.5), max_height=0.5)
+    h = shape.heightfield
+    m, v, grad_h = torch.zeros_like(h), torch.zeros_like(h), torch.zeros_like(h)
+    t = torch.empty(R, device=dev); uv = torch.empty((2, R), device=dev); prim = torch.empty(R, dtype=torch.int32, device=dev)
+    si = torch.empty((18, R), device=dev); gsi = torch.zeros((18, R), device=dev)
+    images = torch.empty((K, npix), device=dev); gimg = torch.empty((K, npix), device=dev)
+    hist = torch.zeros(steps + 1, device=dev)
+    idx = torch.zeros(1, dtype=torch.int64, device=dev)
+    ctr = torch.zeros(1, dtype=torch.int32, device=dev)
+    b1, b2, eps = 0.9, 0.999, 1e-8
+    lr_tab = torch.tensor([lib.hf_adam_lr_t(lr, b1, b2, k + 1) for k in range(steps + 1)], dtype=torch.float32, device=dev)
+    r_s = shape._rays_struct(rays[0:3], rays[3:6], rays[6]); pi_s = shape._pi_struct(t, uv, prim)
+    si_s = _fill(_capi.hf_si_t(), _DIFF_ROWS, _rows(si, R)); g_s = _fill(_capi.hf_si_grad_t(), _DIFF_ROWS, _rows(gsi, R))
+    rows_si, rows_g = _rows(si, R), _rows(gsi, R)
+    shn = (C.c_void_p * 3)(*rows_si[9:12]); gnp = (C.c_void_p * 3)(*rows_g[9:12])
+    dd = (C.c_void_p * 3)(r_s.d[0], r_s.d[1], r_s.d[2])
+    L = (_capi.hf_dir_light_t * K)()
+    for k, (x, y, z, e) in enumerate(lights.tolist()):
+        L[k].to_light[0], L[k].to_light[1], L[k].to_light[2], L[k].irradiance = x, y, z, e
+    flags = int(hf_amd.RayFlags.All)
+
+    def step(stream):
+        grad_h.zero_()
+        _capi.check(lib.hf_ray_intersect(shape._h, R, C.byref(r_s), flags, None, C.byref(pi_s), C.byref(si_s), stream))
+        _capi.check(lib.hf_direct_lighting(R, spp, C.byref(shn), C.byref(dd), rows_si[0], K, L, 1.0, None, images.data_ptr(), stream))
+        diff = images - tgt_img
+        hist.scatter_(0, idx, ((diff * diff).sum() / npix).reshape(1))
+        torch.mul(diff, 2.0 / npix, out=gimg)
+        _capi.check(lib.hf_direct_lighting_adjoint(R, spp, C.byref(shn), C.byref(dd), rows_si[0], K, L, 1.0, None, gimg.data_ptr(),
+                                                   C.byref(gnp), stream))
+        _capi.check(lib.hf_adjoint(shape._h, R, C.byref(r_s), C.byref(pi_s), flags, None, C.byref(g_s), grad_h.data_ptr(),
+                                   None, None, stream))
+        _capi.check(lib.hf_adam_step_scheduled(shape._h, h.data_ptr(), grad_h.data_ptr(), m.data_ptr(), v.data_ptr(),
+                                               lr_tab.data_ptr(), ctr.data_ptr(), b1, b2, eps, 0, stream))
+        idx.add_(1)
+
+    # warm-up outside the capture (code objects load at the first launch), then the state back to step 0
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        step(side.cuda_stream)
+    torch.cuda.current_stream(dev).wait_stream(side)
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        h.fill_(0.5)
+    m.zero_(); v.zero_(); ctr.zero_(); idx.zero_(); hist.zero_()
+    _capi.check(lib.hf_set_heights(shape._h, h.data_ptr(), torch.cuda.current_stream(dev).cuda_stream))
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        step(torch.cuda.current_stream(dev).cuda_stream)
+    # (the capture itself executed nothing)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for it in range(steps):
+        graph.replay()
+        if record is not None:
+            record.append(h.detach().clone())
+    e1.record()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    gpu_ms = e0.elapsed_time(e1)
+    _capi.check(lib.hf_capture_reset(shape._h))
+    err = float((h.detach() - target_h).abs().mean())
+    run_captured.last_centred_error = centred_error(h.detach(), target_h)
+    return hist[:steps].tolist(), err, {"wall_clock_s": wall, "gpu_ms_total": gpu_ms, "wall_ms_per_step": 1e3 * wall / steps,
+                                        "gpu_ms_per_step": gpu_ms / steps}
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--grid", type=int, default=128)
@@ -166,7 +264,13 @@ if __name__ == "__main__":
     ap.add_argument("--aux", type=int, default=8, help="auxiliary rays per primary ray of --silhouette")
     ap.add_argument("--gaussian-film", action="store_true", help="Gaussian reconstruction filter instead of the box film")
     ap.add_argument("--virtual-ranks", type=int, default=0, help="render the tile partition of V ranks on this one device")
+    ap.add_argument("--captured", action="store_true", help="one step captured into a HIP graph and replayed (run_captured)")
     a = ap.parse_args()
+    if a.captured:
+        hist, err, tm = run_captured(a.grid, a.film, a.spp, a.steps, a.lr)
+        print(f"loss {hist[0]:.6f} -> {hist[-1]:.6f}, mean |h - h*| {err:.5f}; {a.steps} replayed steps: {tm['wall_clock_s']:.3f} s wall-clock, "
+              f"{tm['wall_ms_per_step']:.3f} ms per step ({tm['gpu_ms_per_step']:.3f} ms on the GPU)")
+        sys.exit(0)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1:   # torchrun: one process per GPU, RCCL (HF_BENCH_BACKEND=gloo: ranks may share a device)
         import torch.distributed as dist

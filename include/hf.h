@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define HF_VERSION 2 /* 2: hf_reparam_* take ray_id; hf_adjoint_rows, weighted lighting, hf_capture_reset */
+#define HF_VERSION 3 /* 2: hf_reparam_* take ray_id; hf_adjoint_rows, weighted lighting, hf_capture_reset; 3: hf_adam_step_scheduled */
 
 /* status codes */
 enum {
@@ -187,11 +187,25 @@ int hf_set_heights_host(hf_field_t *hf, const float *h_heights, hf_stream_t stre
  * divides by sqrt(max over the texture of v) + eps instead of the per-texel sqrt(v) + eps (two launches).
  * The hyper-parameters are host doubles like the reference's Python scalars: the bias-correction scale is
  * evaluated in double and rounded once (optimizers.py:267-268), everything else runs in float32.
+ * SERIAL PER HANDLE: the uniform variant keeps its running maximum in one device word owned by the handle, and the
+ * rebuild writes the handle's acceleration data -- issue the steps of one handle on one stream (or order them yourself).
+ * A NaN second moment makes the uniform step NaN everywhere (the maximum keeps it), as dr.max over a NaN does in the
+ * reference; the reference holds no fixture for that case (parity unpinned).
  */
 #define HF_ADAM_MASK_UPDATES 1
 #define HF_ADAM_UNIFORM 2
 int hf_adam_step(hf_field_t *hf, float *d_heights, const float *d_grad, float *d_m, float *d_v, double lr,
                  double beta1, double beta2, double eps, uint32_t step, int mask_updates, hf_stream_t stream);
+/* hf_adam_step for CAPTURED steps (HIP graphs).  hf_adam_step bakes the step number into its launch (the bias-corrected
+ * step size lr_t is a kernel argument computed on the host), so a captured step would replay step 1 for ever.  Here
+ * the step sizes come from DEVICE memory: d_lr_t[k] = hf_adam_lr_t(lr, beta1, beta2, k + 1) for the steps the caller
+ * intends to run (filled once, on the host, with hf_adam_step's own arithmetic: bit-identical updates), and *d_step
+ * (device, zero before the first step) selects the entry and is incremented on the stream after the update -- every
+ * replay of the captured step is the next Adam step.  Same mask_updates bits, same rebuild, serial per handle. */
+float hf_adam_lr_t(double lr, double beta1, double beta2, uint32_t step);
+int hf_adam_step_scheduled(hf_field_t *hf, float *d_heights, const float *d_grad, float *d_m, float *d_v,
+                           const float *d_lr_t, uint32_t *d_step, double beta1, double beta2, double eps,
+                           int mask_updates, hf_stream_t stream);
 
 /* Replaces: m_to_world update + update() (rectangle.cpp:101-112, 131-142). */
 int hf_set_transform(hf_field_t *hf, const float to_world[12], const float *to_object_or_null);

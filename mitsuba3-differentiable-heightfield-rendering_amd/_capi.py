@@ -51,6 +51,9 @@ SYMBOLS = {
     "hf_set_heights_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "hf_adam_step": (C.c_int, [C.c_void_p, _fp, _fp, _fp, _fp, C.c_double, C.c_double, C.c_double, C.c_double,
                                C.c_uint32, C.c_int, C.c_void_p]),
+    "hf_adam_lr_t": (C.c_float, [C.c_double, C.c_double, C.c_double, C.c_uint32]),
+    "hf_adam_step_scheduled": (C.c_int, [C.c_void_p, _fp, _fp, _fp, _fp, _fp, _fp, C.c_double, C.c_double, C.c_double, C.c_int,
+                                         C.c_void_p]),
     "hf_set_transform": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "hf_bbox": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "hf_heights_device": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),

@@ -303,9 +303,31 @@ extern "C" int hf_adam_step(hf_field_t *hf, float *d_heights, const float *d_gra
     const float lr_scale = (float) (sqrt(1.0 - pow(beta2, (double) step)) / (1.0 - pow(beta1, (double) step)));
     const float lr_t = (float) lr * lr_scale;
     // mask_updates: bit 0 = mask_updates, bit 1 = the 'uniform' variant (optimizers.py:259, 290-291)
-    hf_launch_adam((size_t) hf->dev.W * hf->dev.H, d_heights, d_grad, d_m, d_v, lr_t, (float) beta1, (float) beta2,
-                   (float) (1.0 - beta1), (float) (1.0 - beta2), (float) eps, mask_updates & 1, (hipStream_t) stream,
-                   (mask_updates & 2) ? hf->d_misc : nullptr);
+    HF_HIP(hf_launch_adam((size_t) hf->dev.W * hf->dev.H, d_heights, d_grad, d_m, d_v, lr_t, (float) beta1, (float) beta2,
+                          (float) (1.0 - beta1), (float) (1.0 - beta2), (float) eps, mask_updates & 1, (hipStream_t) stream,
+                          (mask_updates & 2) ? hf->d_misc : nullptr));
+    HF_HIP(hipGetLastError());
+    return hf_set_heights(hf, d_heights, stream);
+}
+
+extern "C" float hf_adam_lr_t(double lr, double beta1, double beta2, uint32_t step) {
+    // the arithmetic of hf_adam_step: lr_scale in double, rounded once, times the float learning rate
+    const float lr_scale = (float) (sqrt(1.0 - pow(beta2, (double) step)) / (1.0 - pow(beta1, (double) step)));
+    return (float) lr * lr_scale;
+}
+
+extern "C" int hf_adam_step_scheduled(hf_field_t *hf, float *d_heights, const float *d_grad, float *d_m, float *d_v,
+                                      const float *d_lr_t, uint32_t *d_step, double beta1, double beta2, double eps,
+                                      int mask_updates, hf_stream_t stream) {
+    if (!hf || !d_heights || !d_grad || !d_m || !d_v || !d_lr_t || !d_step)
+        return fail(HF_EINVAL, "hf_adam_step_scheduled: NULL argument");
+    if (!(beta1 >= 0. && beta1 < 1.) || !(beta2 >= 0. && beta2 < 1.) || !(eps > 0.))
+        return fail(HF_EINVAL, "hf_adam_step_scheduled: need 0 <= beta < 1, eps > 0");
+    hf_device_guard guard(hf->device);
+    if (!guard.ok) return fail(HF_EDEVICE, "hf_adam_step_scheduled: cannot select device %d", hf->device);
+    HF_HIP(hf_launch_adam((size_t) hf->dev.W * hf->dev.H, d_heights, d_grad, d_m, d_v, 0.f, (float) beta1, (float) beta2,
+                          (float) (1.0 - beta1), (float) (1.0 - beta2), (float) eps, mask_updates & 1, (hipStream_t) stream,
+                          (mask_updates & 2) ? hf->d_misc : nullptr, d_lr_t, d_step));
     HF_HIP(hipGetLastError());
     return hf_set_heights(hf, d_heights, stream);
 }

@@ -494,6 +494,46 @@ __device__ __forceinline__ bool setup_ray(const hf_dev_field &f, float2 zr, v3 o
     return true;
 }
 
+// Conservative twin of setup_ray's clip: false ONLY IF setup_ray would return false for this ray (it may say true for a
+// ray setup_ray rejects: that ray just takes the ordinary path).  Same formulas with v_rcp_f32 instead of the three IEEE
+// divisions, every quantity that enters the decision pushed to the safe side by 1e-5 relative (the reciprocals are off
+// by one ulp, the products by half an ulp each: 3e-7), a ray with a zero direction component or a non-finite one is
+// "maybe".  Used by the wide path of the traversal kernels for fetches that miss the bound as a whole.
+__device__ __forceinline__ bool maybe_alive(const hf_dev_field &f, float2 zr, v3 o, v3 d, float maxt) {
+    const v3 oo = xform_point(f.to_object, o), od = xform_vec(f.to_object, d);
+    const float chk = (oo.x + oo.y + oo.z) + (od.x + od.y + od.z);
+    if (!(__builtin_fabsf(chk) < __builtin_inff()) || !(maxt >= 0.f)) return true; // (setup_ray: a miss; left to it)
+    if (!(__builtin_fabsf(od.x) >= 1e-30f) || !(__builtin_fabsf(od.y) >= 1e-30f) || !(__builtin_fabsf(od.z) >= 1e-30f)) return true; // (zero / denormal: 1/d overflows)
+    const float zspan = fmaxf(zr.y - zr.x, fmaxf(__builtin_fabsf(zr.x), __builtin_fabsf(zr.y)));
+    const float mz0 = 1e-5f * zspan + 1e-30f;
+    const float oc[3] = { oo.x, oo.y, oo.z }, dc[3] = { od.x, od.y, od.z };
+    float rr[3], tin0 = 0.f;
+    {
+        const float lo[3] = { -1.f - 1e-4f, -1.f - 1e-4f, zr.x - mz0 };
+        const float hi[3] = { 1.f + 1e-4f, 1.f + 1e-4f, zr.y + mz0 };
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            rr[k] = __builtin_amdgcn_rcpf(dc[k]);
+            tin0 = fmaxf(tin0, fminf((lo[k] - oc[k]) * rr[k], (hi[k] - oc[k]) * rr[k]));
+        }
+        tin0 = fmaxf(tin0, 0.f) * (1.f + 1e-5f); // an UPPER bound of setup_ray's tin0
+    }
+    const float reach = (__builtin_fabsf(oo.x) + __builtin_fabsf(oo.y) + tin0 * (__builtin_fabsf(od.x) + __builtin_fabsf(od.y)) + 2.f) * (1.f + 1e-5f);
+    const float far = fmaxf(1.f, 0.125f * reach);
+    const float m = (HF_M0 + fminf(8.f, 4.8e-7f * reach * fmaxf(f.hx, f.hy) * (far * far))) * (1.f + 1e-5f); // >= setup_ray's m
+    const float ex = 1e-4f + m * f.sx, ey = 1e-4f + m * f.sy, ez = __builtin_fmaf(2.f * m, zspan, mz0);
+    const float lo[3] = { -1.f - ex, -1.f - ey, zr.x - ez }, hi[3] = { 1.f + ex, 1.f + ey, zr.y + ez }; // contain setup_ray's box
+    float tin = 0.f, tout = maxt;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float t1 = (lo[k] - oc[k]) * rr[k], t2 = (hi[k] - oc[k]) * rr[k];
+        tin = fmaxf(tin, fminf(t1, t2));
+        tout = fminf(tout, fmaxf(t1, t2));
+    }
+    // setup_ray keeps the ray when tin (1 - 1e-6) <= tout (1 + 1e-6); here both sides carry the reciprocals' error on top
+    return tin - __builtin_fabsf(tin) * 1e-5f <= tout + __builtin_fabsf(tout) * 1e-5f;
+}
+
 // The ray in the sheared coordinate  w = z - (c + a (x - xc) + b (y - yc))  of a node whose centre is
 // (xc,yc) in order space: w(t) = gz + t dz.  (a,b) are stored for actual coordinates; mirroring an
 // axis into order space flips the sign of its slope.  mz grows by the slope times the xy uncertainty
@@ -1224,6 +1264,9 @@ struct hf_si_dev {
 // record stores are write-once streams (72 B/ray): non-temporal, so that they do not push the mip
 // and height lines of concurrently traversing waves out of L2.  Address = (row + ub) + lo: uniform base, lane offset.
 __device__ __forceinline__ void st(float *p, size_t ub, uint32_t lo, float v) { if (p) __builtin_nontemporal_store(v, &(p + ub)[lo]); }
+typedef float f4 __attribute__((ext_vector_type(4)));
+// four consecutive entries of a row per lane (the wide path): (row + ub) as 16-byte elements, lane offset l4
+__device__ __forceinline__ void st4(float *p, size_t ub, uint32_t l4, f4 v) { if (p) __builtin_nontemporal_store(v, &((f4 *) (p + ub))[l4]); }
 #define st3(p, ub, lo, v) do { st((p)[0], ub, lo, (v).x); st((p)[1], ub, lo, (v).y); st((p)[2], ub, lo, (v).z); } while (0)
 
 #ifndef HF_GRAB
@@ -1257,6 +1300,7 @@ struct hf_trace_args {
     hf_si_dev sio;
     uint32_t flags;
     uint32_t grab; // rays per fetch, a multiple of 64
+    uint32_t wide; // every ray / record row is 16-byte aligned and there is no `active` mask: fetches that miss the bound as a whole take the wide path
     unsigned long long *counter;
     unsigned long long n_grabs; // ceil(n / grab)
     // fused mode only: trace auxiliary ray aux_k of every ray instead of the ray itself (hf_reparam_trace): the
@@ -1371,6 +1415,65 @@ __global__ __launch_bounds__(HF_BLOCK, (MODE == 2 ? HF_TRACE_WAVES_FUSED : HF_TR
         float maxt = 0.f;
 #pragma unroll 1
         for (unsigned sub = 0; sub < grab; sub += 64) {
+            if (!AUX && (sub & 255u) == 0u) {
+                // ---- WIDE PATH: 256 rays that miss the bound as a whole (70 % of the bench wavefront) ----
+                // Four rays per lane through 16-byte loads, the conservative clip (maybe_alive: false only where setup_ray
+                // says false), and if nobody may enter the bound the 256 miss records go out as 16-byte stores: 37 memory
+                // instructions and ~360 others per 256 rays where four ordinary batches take ~1900 -- and a quarter of the
+                // memory round trips, i.e. of the time the wave holds its slot.  A fetch with any "maybe" ray takes the
+                // ordinary path below (its rays are re-read: L2 hits).
+                const __attribute__((address_space(4))) hf_trace_args *kw =
+                    (const __attribute__((address_space(4))) hf_trace_args *) __builtin_amdgcn_kernarg_segment_ptr();
+                asm volatile("" : "+s"(kw));
+                const size_t ubw = base + sub;
+                if (kw->wide != 0u && sub + 256u <= grab && ubw + 256u <= kw->n) { // wave-uniform
+                    const uint32_t l4 = lane; // lane l: rays ubw + 4 l .. 4 l + 3
+                    const hf_rays_dev rp = load_rays(kw);
+                    const f4 ox = ((const f4 *) (rp.o[0] + ubw))[l4], oy = ((const f4 *) (rp.o[1] + ubw))[l4], oz = ((const f4 *) (rp.o[2] + ubw))[l4];
+                    const f4 dx = ((const f4 *) (rp.d[0] + ubw))[l4], dy = ((const f4 *) (rp.d[1] + ubw))[l4], dz = ((const f4 *) (rp.d[2] + ubw))[l4];
+                    const f4 mt = ((const f4 *) (rp.maxt + ubw))[l4];
+                    bool maybe = false;
+                    {
+                        const hf_dev_field f0 = load_field(&kw->f);
+                        const float2 zr = f0.mip[1];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) maybe |= maybe_alive(f0, zr, mk3(ox[j], oy[j], oz[j]), mk3(dx[j], dy[j], dz[j]), mt[j]);
+                    }
+                    if (__ballot(maybe) == 0ull) {
+                        // (opaque: constant register quadruples are otherwise hoisted out of the kernel's persistent loop,
+                        // spilled, and re-loaded before every store)
+                        float z0 = 0.f, i0 = __builtin_inff();
+                        asm volatile("" : "+v"(z0), "+v"(i0));
+                        const f4 zero = { z0, z0, z0, z0 };
+                        if (MODE == 1) {
+                            ((uint32_t *) (kw->hit_out + ubw))[l4] = 0u;
+                        } else {
+                            const f4 inf4 = { i0, i0, i0, i0 };
+                            const hf_pi_dev pi = load_pi(kw);
+                            if (pi.t) st4(pi.t, ubw, l4, inf4);
+                            if (pi.u) st4(pi.u, ubw, l4, zero);
+                            if (pi.v) st4(pi.v, ubw, l4, zero);
+                            if (pi.prim) st4((float *) pi.prim, ubw, l4, zero);
+                            if (MODE == 2) { // zero-initialised record (interaction.h:479-499, 667-673), wi = -d
+                                const uint32_t flags = kw->flags;
+                                const hf_si_dev sd = load_si(kw);
+                                st4(sd.t, ubw, l4, inf4);
+#pragma unroll
+                                for (int c = 0; c < 3; ++c) {
+                                    st4(sd.p[c], ubw, l4, zero); st4(sd.n[c], ubw, l4, zero); st4(sd.sh_n[c], ubw, l4, zero);
+                                    st4(sd.dp_du[c], ubw, l4, zero); st4(sd.dp_dv[c], ubw, l4, zero);
+                                    st4(sd.sh_s[c], ubw, l4, zero); st4(sd.sh_t[c], ubw, l4, zero);
+                                }
+                                st4(sd.uv[0], ubw, l4, zero); st4(sd.uv[1], ubw, l4, zero);
+                                if (flags & 0x40u) { const float b0 = z0 + 1e8f; const f4 big = { b0, b0, b0, b0 }; st4(sd.bt, ubw, l4, big); }
+                                st4(sd.wi[0], ubw, l4, -dx); st4(sd.wi[1], ubw, l4, -dy); st4(sd.wi[2], ubw, l4, -dz);
+                            }
+                        }
+                        sub += 192u; // (+ 64 by the loop: the next fetch of the grab)
+                        continue;
+                    }
+                }
+            }
             // all 64 lanes stay in the loop body (the shared walk relies on whole-wave ballots);
             // lanes past the end of the wavefront re-read the last ray and store nothing.
             // Pointers and constants that are only needed before or after the walk are read from the kernarg
@@ -1387,7 +1490,7 @@ __global__ __launch_bounds__(HF_BLOCK, (MODE == 2 ? HF_TRACE_WAVES_FUSED : HF_TR
             const size_t left = n - ub; // >= 1
             const bool valid = lane < left;
             const uint32_t lo = valid ? lane : (uint32_t) (left - 1);
-            if (sub == 0) {
+            if ((sub & 255u) == 0u) { // first batch of a fetch: nothing was requested ahead (see the end of the body)
                 const hf_rays_dev rp = load_rays(ka);
                 o = mk3((rp.o[0] + ub)[lo], (rp.o[1] + ub)[lo], (rp.o[2] + ub)[lo]);
                 d = mk3((rp.d[0] + ub)[lo], (rp.d[1] + ub)[lo], (rp.d[2] + ub)[lo]);
@@ -1452,7 +1555,7 @@ __global__ __launch_bounds__(HF_BLOCK, (MODE == 2 ? HF_TRACE_WAVES_FUSED : HF_TR
             // complete in order, so a wave that loads after its stores waits for the store acknowledgements
             // (HBM write latency) on top of its own load latency -- that serial chain, not bandwidth, bounded
             // the rays that only stream.
-            if (sub + 64 < grab && ub + 64 < n) {
+            if (((sub + 64u) & 255u) != 0u && sub + 64 < grab && ub + 64 < n) { // (the next fetch decides about its own rays)
                 const size_t ub2 = ub + 64, left2 = n - ub2;
                 const uint32_t lo2 = lane < left2 ? lane : (uint32_t) (left2 - 1);
                 const hf_rays_dev rp = load_rays(ka);
@@ -1575,6 +1678,18 @@ void hf_launch_trace(int mode, const hf_dev_field &f, size_t n, const hf_rays_t 
     hf_trace_args a;
     a.f = f; a.n = n; a.rays = r; a.active = active; a.pi = p; a.hit_out = hit; a.sio = sd; a.flags = flags;
     a.counter = (unsigned long long *) scratch; a.grab = grab;
+    {   // the wide path reads and writes 16 bytes per lane: every row it touches must be 16-byte aligned
+        uintptr_t bits = 0;
+        for (int k = 0; k < 3; ++k) bits |= (uintptr_t) r.o[k] | (uintptr_t) r.d[k];
+        bits |= (uintptr_t) r.maxt | (uintptr_t) p.t | (uintptr_t) p.u | (uintptr_t) p.v | (uintptr_t) p.prim;
+        if (mode == 1) bits |= (uintptr_t) hit << 2; // (4 bytes per lane)
+        const float *const *rows = (const float *const *) &sd;
+        for (size_t k = 0; k < sizeof(sd) / sizeof(float *); ++k) bits |= (uintptr_t) rows[k];
+        a.wide = (active == nullptr && (bits & 15u) == 0u && grab % 256u == 0u) ? 1u : 0u;
+#ifdef HF_NO_WIDE
+        a.wide = 0u;
+#endif
+    }
     a.n_grabs = waves;
     a.aux_on = 0u; a.aux_k = 0u; a.aux_seed = 0u; a.aux_kappa = 1.f; a.aux_antithetic = 0; a.aux_ray_id = nullptr;
     if (aux && mode == 2) {
@@ -2154,10 +2269,14 @@ void hf_launch_reparam_backward(const hf_dev_field &f, const hf_reparam_args &ra
 // ---------------------------------------------------------------------------------
 // Adam step on the height texture (optimizers.py:263-300), explicit operation order (no contraction)
 // ---------------------------------------------------------------------------------
+// (sched, ctr): hf_adam_step_scheduled -- the step size is sched[*ctr] (a host-filled table of the bias-corrected step
+// sizes, so that a captured step can be replayed: the step number is not baked into the launch); else lr_t
 __global__ __launch_bounds__(HF_BLOCK) void hf_adam_kernel(size_t n, float *__restrict__ h, const float *__restrict__ g,
                                                           float *__restrict__ m, float *__restrict__ v, float lr_t,
                                                           float beta1, float beta2, float c1, float c2, float eps,
-                                                          int mask_updates) {
+                                                          int mask_updates, const float *__restrict__ sched,
+                                                          const uint32_t *__restrict__ ctr) {
+    if (sched) lr_t = sched[*ctr];
     const size_t stride = (size_t) gridDim.x * HF_BLOCK;
     for (size_t i = (size_t) blockIdx.x * HF_BLOCK + threadIdx.x; i < n; i += stride) {
         const float gi = g[i];
@@ -2185,14 +2304,17 @@ __global__ __launch_bounds__(HF_BLOCK) void hf_adam_moments_kernel(size_t n, con
             vt = beta2 * vt + c2 * (gi * gi);
             v[i] = vt;
         }
-        mx = fmaxf(mx, vt); // dr.max(v_t) runs over every entry, masked ones with their old value (:282-285, 290)
+        mx = (vt != vt) ? vt : fmaxf(mx, vt); // dr.max(v_t) runs over every entry, masked ones with their old value (:282-285, 290); a NaN moment is kept (fmaxf would drop it and mask a diverged run)
     }
-    const uint32_t wm = wave_max_u32(__builtin_bit_cast(uint32_t, mx));
+    // (as unsigned bits: v >= 0, and a NaN -- 0x7fc00000 and up -- is larger than every finite value, so it reaches *vmax)
+    const uint32_t wm = wave_max_u32(__builtin_bit_cast(uint32_t, mx) & 0x7FFFFFFFu);
     if ((threadIdx.x & 63u) == 0u && wm > __hip_atomic_load(vmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(vmax, wm);
 }
 __global__ __launch_bounds__(HF_BLOCK) void hf_adam_apply_uniform_kernel(size_t n, float *__restrict__ h, const float *__restrict__ g,
                                                                         const float *__restrict__ m, float lr_t, float eps,
-                                                                        int mask_updates, const uint32_t *vmax) {
+                                                                        int mask_updates, const uint32_t *vmax,
+                                                                        const float *__restrict__ sched, const uint32_t *__restrict__ ctr) {
+    if (sched) lr_t = sched[*ctr];
     const float den = __builtin_sqrtf(__builtin_bit_cast(float, *vmax)) + eps;
     const size_t stride = (size_t) gridDim.x * HF_BLOCK;
     for (size_t i = (size_t) blockIdx.x * HF_BLOCK + threadIdx.x; i < n; i += stride) {
@@ -2201,19 +2323,25 @@ __global__ __launch_bounds__(HF_BLOCK) void hf_adam_apply_uniform_kernel(size_t 
     }
 }
 
-void hf_launch_adam(size_t n, float *h, const float *g, float *m, float *v, float lr_t, float beta1, float beta2,
-                    float c1, float c2, float eps, int mask_updates, hipStream_t stream, uint32_t *uniform_scratch) {
-    if (n == 0) return;
+__global__ void hf_counter_increment_kernel(uint32_t *ctr) { *ctr += 1u; }
+
+hipError_t hf_launch_adam(size_t n, float *h, const float *g, float *m, float *v, float lr_t, float beta1, float beta2,
+                          float c1, float c2, float eps, int mask_updates, hipStream_t stream, uint32_t *uniform_scratch,
+                          const float *sched, uint32_t *ctr) {
+    if (n == 0) return hipSuccess;
     if (uniform_scratch) {
-        (void) hipMemsetAsync(uniform_scratch, 0, sizeof(uint32_t), stream);
+        const hipError_t e = hipMemsetAsync(uniform_scratch, 0, sizeof(uint32_t), stream);
+        if (e != hipSuccess) return e; // (the reduction below would start from a stale maximum)
         hipLaunchKernelGGL(hf_adam_moments_kernel, dim3(grid_for(n)), dim3(HF_BLOCK), 0, stream, n, g, m, v, beta1, beta2, c1, c2,
                            mask_updates, uniform_scratch);
         hipLaunchKernelGGL(hf_adam_apply_uniform_kernel, dim3(grid_for(n)), dim3(HF_BLOCK), 0, stream, n, h, g, m, lr_t, eps,
-                           mask_updates, uniform_scratch);
-        return;
+                           mask_updates, uniform_scratch, sched, (const uint32_t *) ctr);
+    } else {
+        hipLaunchKernelGGL(hf_adam_kernel, dim3(grid_for(n)), dim3(HF_BLOCK), 0, stream, n, h, g, m, v, lr_t, beta1, beta2,
+                           c1, c2, eps, mask_updates, sched, (const uint32_t *) ctr);
     }
-    hipLaunchKernelGGL(hf_adam_kernel, dim3(grid_for(n)), dim3(HF_BLOCK), 0, stream, n, h, g, m, v, lr_t, beta1, beta2,
-                       c1, c2, eps, mask_updates);
+    if (sched) hipLaunchKernelGGL(hf_counter_increment_kernel, dim3(1), dim3(1), 0, stream, ctr); // the next replay's step
+    return hipSuccess;
 }
 
 // ---------------------------------------------------------------------------------

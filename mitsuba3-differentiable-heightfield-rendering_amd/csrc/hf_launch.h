@@ -22,9 +22,9 @@ void hf_launch_adjoint(const hf_dev_field &f, size_t n, const hf_rays_t *rays, c
                        float *const grad_o[3], float *const grad_d[3], uint32_t *row_band, hipStream_t stream);
 // c1 = (float)(1 - beta1), c2 = (float)(1 - beta2): the differences are Python doubles in optimizers.py:279-280,
 // rounded once when they meet the float32 gradient
-void hf_launch_adam(size_t n, float *h, const float *g, float *m, float *v, float lr_t, float beta1, float beta2,
+hipError_t hf_launch_adam(size_t n, float *h, const float *g, float *m, float *v, float lr_t, float beta1, float beta2,
                     float c1, float c2, float eps, int mask_updates, hipStream_t stream,
-                    uint32_t *uniform_scratch = nullptr); // non-NULL: the UniformAdam variant (one device word of scratch)
+                    uint32_t *uniform_scratch = nullptr, const float *sched = nullptr, uint32_t *ctr = nullptr); // non-NULL: the UniformAdam variant (one device word of scratch)
 struct hf_lights_dev {
     float l[HF_MAX_LIGHTS][3];
     float w[HF_MAX_LIGHTS]; // albedo/pi * irradiance

@@ -24,11 +24,26 @@ def _run(cmd, extra_env):
     return json.loads(lines[0])
 
 
+def _free_port():
+    import socket
+    with socket.socket() as s:   # bind to port 0: the kernel picks a free one (a hard-coded port fails when it is busy)
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def test_two_ranks_over_gloo_equal_one_rank(hf):
     one = _run([sys.executable, "bench.py", "--gpus", "1"] + SIZE, {})
     two = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                "--master-addr", "127.0.0.1", "--master-port", "29531", "bench.py", "--gpus", "2"] + SIZE,
+                "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), "bench.py", "--gpus", "2"] + SIZE,
                {"HF_BENCH_BACKEND": "gloo"})
+    # the line describes the collective it ran: backend and world size as the process group reports them, one entry per rank
+    col = two["collective"]
+    assert col["backend"] == "gloo" and col["world_size"] == 2 and [r["rank"] for r in col["ranks"]] == [0, 1]
+    assert all(r["host"] and r["name"] and r["device"] is not None for r in col["ranks"])
+    assert one["collective"] is None
+    for line in (one, two):   # which library the numbers come from
+        assert line["library"]["path"].endswith("libhf.so") and len(line["library"]["sha256_16"]) == 16
+        assert line["library"]["hf_lib_override"] == bool(os.environ.get("HF_LIB"))
     R = 512 * 512 * 16
     assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["scaling"] == "strong"
     assert one["config"]["rays_per_step"] == R and two["config"]["rays_per_step"] == R     # sum over ranks = the one wavefront

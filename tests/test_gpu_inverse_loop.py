@@ -152,6 +152,32 @@ def test_sharded_loop_equals_the_unsharded_loop(hf):
     assert float((one[9] - one[0]).abs().max()) > 0.05     # the trajectory is not trivial
 
 
+def test_captured_loop_equals_the_eager_loop(hf):
+    """configs[4] with ONE optimisation step captured into a HIP graph and replayed (inverse_heights.run_captured: trace ->
+    lighting -> loss gradient -> lighting adjoint -> hf_adjoint -> hf_adam_step_scheduled, the step size read from a
+    device table because a captured hf_adam_step would replay step 1 for ever) against the eager autograd loop on the
+    same scene: the same kernels on the same inputs, so losses and heights of the first steps agree to the order of the
+    float atomics, and both loops arrive at the same loss (optimizers.py:263-300, util.py:185-232)."""
+    import inverse_heights
+    kw = dict(grid=64, film=96, spp=4, steps=40, lr=0.02)
+    eager, replay = [], []
+    h1, _, _ = inverse_heights.run(record=eager, verbose=False, **kw)
+    h2, err2, tm = inverse_heights.run_captured(record=replay, **kw)
+    assert len(h1) == len(h2) == 40
+    for k in range(5):
+        assert abs(h1[k] - h2[k]) <= 1e-4 * abs(h1[k]), (k, h1[k], h2[k])
+        assert float((eager[k] - replay[k]).abs().max()) <= 2e-4, k
+    assert abs(h1[-1] - h2[-1]) <= 0.02 * abs(h1[-1]) and h2[-1] < 0.5 * h2[0]
+    assert float((replay[9] - replay[0]).abs().max()) > 0.05     # the step number advances across replays
+    assert tm["gpu_ms_per_step"] > 0 and tm["wall_ms_per_step"] >= 0.9 * tm["gpu_ms_per_step"]
+    # the step-size table is hf_adam_step's own arithmetic
+    import math
+    from hf_amd import _capi
+    for step in (1, 2, 17, 1000):
+        want = 0.02 * math.sqrt(1 - 0.999 ** step) / (1 - 0.9 ** step)
+        assert abs(_capi.lib().hf_adam_lr_t(0.02, 0.9, 0.999, step) - want) <= 2e-7 * want
+
+
 def test_weighted_direct_lighting_equals_torch_arithmetic(hf):
     """hf_direct_lighting's per-sample weight row (the determinant of a reparameterised camera ray,
     direct_reparam.py:164-180): image, d/d sh_frame.n and d/d weight against the same shading written in torch."""
