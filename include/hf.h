@@ -407,6 +407,15 @@ int hf_reparam_weights(int mode, size_t n, const float *const o[3], const float 
 int hf_reparam_trace(const hf_field_t *hf, size_t n, const float *const o[3], const float *const d[3],
                      const uint8_t *active, uint32_t k, float kappa, int antithetic, uint32_t seed,
                      const uint32_t *ray_id, const hf_pi_t *out_pi, const hf_si_t *out_si, hf_stream_t stream);
+/* hf_reparam_trace for samples 0 .. num_rays - 1 in ONE launch: sample k of ray i goes to [k * sample_stride + i] of
+ * every row of out_pi / out_si (the layout hf_reparam_backward reads).  A ray is fetched once and its samples are
+ * traced back to back; and because every von Mises-Fisher sample lies within theta_max of the ray (cos theta_max =
+ * 1 - 13.82 / kappa, warp.h:557-566), a batch of rays whose cones all miss the bound is answered with num_rays miss
+ * records without a sample being drawn (not when out_si->wi is asked for).  Bitwise num_rays x hf_reparam_trace. */
+int hf_reparam_trace_all(const hf_field_t *hf, size_t n, const float *const o[3], const float *const d[3],
+                         const uint8_t *active, uint32_t num_rays, float kappa, int antithetic, uint32_t seed,
+                         const uint32_t *ray_id, const hf_pi_t *out_pi, const hf_si_t *out_si, size_t sample_stride,
+                         hf_stream_t stream);
 /* The same backward pass in ONE kernel for the case that only the heights are differentiated (grad(ray) not wanted):
  * for every ray the weights of its num_rays samples and their sums Z, dZ (reparam.py:236-256), then for every
  * auxiliary HIT the gradient of its V_direct through the FollowShape surface interaction into grad_heights[H*W]

@@ -100,6 +100,8 @@ SYMBOLS = {
                                      C.POINTER(_fp * 3), C.c_void_p]),
     "hf_reparam_trace": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(_fp * 3), C.POINTER(_fp * 3), _fp, C.c_uint32, C.c_float,
                                    C.c_int, C.c_uint32, C.c_void_p, C.POINTER(hf_pi_t), C.POINTER(hf_si_t), C.c_void_p]),
+    "hf_reparam_trace_all": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(_fp * 3), C.POINTER(_fp * 3), _fp, C.c_uint32, C.c_float,
+                                       C.c_int, C.c_uint32, C.c_void_p, C.POINTER(hf_pi_t), C.POINTER(hf_si_t), C.c_size_t, C.c_void_p]),
     "hf_reparam_backward": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(_fp * 3), C.POINTER(_fp * 3), _fp, C.c_uint32,
                                       C.c_float, C.c_float, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, _fp, C.c_size_t,
                                       C.POINTER(_fp * 3), _fp, _fp, C.c_void_p]),

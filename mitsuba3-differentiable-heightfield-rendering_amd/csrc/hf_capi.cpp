@@ -740,6 +740,33 @@ extern "C" int hf_reparam_trace(const hf_field_t *hf, size_t n, const float *con
     return HF_OK;
 }
 
+extern "C" int hf_reparam_trace_all(const hf_field_t *hf, size_t n, const float *const o[3], const float *const d[3],
+                                    const uint8_t *active, uint32_t num_rays, float kappa, int antithetic, uint32_t seed,
+                                    const uint32_t *ray_id, const hf_pi_t *out_pi, const hf_si_t *out_si, size_t sample_stride,
+                                    hf_stream_t stream) {
+    if (!all3(o) || !all3(d)) return fail(HF_EINVAL, "hf_reparam_trace_all: NULL argument");
+    hf_rays_t rays; // maxt is not read for auxiliary rays (infinity); any readable array of n floats will do
+    for (int c = 0; c < 3; ++c) { rays.o[c] = o[c]; rays.d[c] = d[c]; }
+    rays.maxt = o[0];
+    int rc = check_rays("hf_reparam_trace_all", hf, n, &rays);
+    if (rc) return rc;
+    if (!out_si) return fail(HF_EINVAL, "hf_reparam_trace_all: NULL output");
+    if (!(kappa > 0.f)) return fail(HF_EINVAL, "hf_reparam_trace_all: kappa must be > 0");
+    if (num_rays == 0 || num_rays > 32) return fail(HF_EINVAL, "hf_reparam_trace_all: 1..32 auxiliary rays per ray (got %u)", num_rays);
+    if (num_rays > 1 && sample_stride < n) return fail(HF_EINVAL, "hf_reparam_trace_all: sample_stride < n");
+    if (n >= ((size_t) 1 << 32)) return fail(HF_EINVAL, "hf_reparam_trace_all: more than 2^32 rays");
+    hf_reparam_args a = {};
+    a.k = 0; a.num = num_rays; a.stride = sample_stride; a.seed = seed; a.kappa = kappa; a.antithetic = antithetic; a.ray_id = ray_id;
+    {
+        slot_lease lease(hf, (hipStream_t) stream, hf_trace_scratch_bytes(n));
+        if (!lease.buf) return fail(lease.code, "trace launch: %s", lease.why);
+        hf_launch_trace(2, hf->dev, n, &rays, active, out_pi, nullptr, out_si,
+                        HF_RAY_ALL | HF_RAY_FOLLOWSHAPE | HF_RAY_BOUNDARYTEST, lease.buf, (hipStream_t) stream, &a);
+    }
+    HF_HIP(hipGetLastError());
+    return HF_OK;
+}
+
 extern "C" int hf_reparam_backward(const hf_field_t *hf, size_t n, const float *const o[3], const float *const d[3],
                                    const uint8_t *active, uint32_t num_rays, float kappa, float exponent,
                                    int antithetic, uint32_t seed, const uint32_t *ray_id, const hf_pi_const_t *pi,

@@ -534,6 +534,51 @@ __device__ __forceinline__ bool maybe_alive(const hf_dev_field &f, float2 zr, v3
     return tin - __builtin_fabsf(tin) * 1e-5f <= tout + __builtin_fabsf(tout) * 1e-5f;
 }
 
+// All auxiliary rays of a ray at once (hf_reparam_trace_all): false ONLY IF no von Mises-Fisher sample around d can
+// pass setup_ray's clip.  Every sample lies within the angle theta_max of d (warp.h:557-566 with its clamp of the
+// sample at 1e-6: cos theta >= 1 - 13.82 / kappa), so at the parameter tau of the primary ray's object-space line the
+// auxiliary point is at most tau x ct away from it, ct = sqrt(2) ||to_object|| tan(theta_max) (launcher); an auxiliary
+// hit lies in the bound, hence at tau <= (R + |o - c|) / (|d_obj| - ct) (R: radius of the inflated bound around its
+// centre c), so the primary ray has to pass the bound inflated by r_max = that tau x ct on every axis -- tested like
+// maybe_alive (v_rcp_f32, decisions pushed to the safe side).  "Maybe" whenever an assumption of the bound fails: a
+// direction that is not unit length (the frame is then not orthonormal), an inflation of more than a tenth of the
+// bound (tiny grids, far origins), |d_obj| <= ct.
+__device__ __forceinline__ bool cone_maybe_alive(const hf_dev_field &f, float2 zr, v3 o, v3 d, float ct) {
+    const v3 oo = xform_point(f.to_object, o), od = xform_vec(f.to_object, d);
+    const float chk = (oo.x + oo.y + oo.z) + (od.x + od.y + od.z);
+    if (!(__builtin_fabsf(chk) < __builtin_inff())) return true;
+    if (!(__builtin_fabsf(dot3(d, d) - 1.f) <= 1e-3f)) return true;
+    if (!(__builtin_fabsf(od.x) >= 1e-30f) || !(__builtin_fabsf(od.y) >= 1e-30f) || !(__builtin_fabsf(od.z) >= 1e-30f)) return true;
+    const float zspan = fmaxf(zr.y - zr.x, fmaxf(__builtin_fabsf(zr.x), __builtin_fabsf(zr.y)));
+    const float mz0 = 1e-5f * zspan + 1e-30f;
+    const float zc = 0.5f * (zr.x + zr.y), zh = 0.5f * (zr.y - zr.x);
+    const float zcap = 0.1f * zh + 0.1f * zspan + 1e-3f; // the z inflation R allows for (x, y: 0.1)
+    const float dz0 = oo.z - zc;
+    const float dist = __builtin_sqrtf(__builtin_fmaf(dz0, dz0, __builtin_fmaf(oo.y, oo.y, oo.x * oo.x))) * (1.f + 1e-5f);
+    const float hzc = zh + zcap;
+    const float R = __builtin_sqrtf(__builtin_fmaf(hzc, hzc, 2.42f)) * (1.f + 1e-5f); // half diagonal of (1.1, 1.1, zh + zcap)
+    // no auxiliary ray travels further to the bound than this (cf. setup_ray's reach): an upper bound of every sample's m
+    const float reach = (__builtin_fabsf(oo.x) + __builtin_fabsf(oo.y) + 1.4143f * (dist + R) + 2.f) * (1.f + 1e-5f);
+    const float far = fmaxf(1.f, 0.125f * reach);
+    const float m = (HF_M0 + fminf(8.f, 4.8e-7f * reach * fmaxf(f.hx, f.hy) * (far * far))) * (1.f + 1e-5f);
+    const float ex = 1e-4f + m * f.sx, ey = 1e-4f + m * f.sy, ez = __builtin_fmaf(2.f * m, zspan, mz0);
+    if (!(ex <= 0.1f) || !(ey <= 0.1f) || !(ez <= zcap)) return true;
+    const float den = __builtin_sqrtf(dot3(od, od)) * (1.f - 1e-5f) - ct;
+    if (!(den > 0.f)) return true;
+    const float rmax = (R + dist) * __builtin_amdgcn_rcpf(den) * ct * (1.f + 1e-4f);
+    const float lo[3] = { -1.f - ex - rmax, -1.f - ey - rmax, zr.x - ez - rmax }, hi[3] = { 1.f + ex + rmax, 1.f + ey + rmax, zr.y + ez + rmax };
+    const float oc[3] = { oo.x, oo.y, oo.z }, dc[3] = { od.x, od.y, od.z };
+    float tin = 0.f, tout = __builtin_inff();
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float r = __builtin_amdgcn_rcpf(dc[k]);
+        const float t1 = (lo[k] - oc[k]) * r, t2 = (hi[k] - oc[k]) * r;
+        tin = fmaxf(tin, fminf(t1, t2));
+        tout = fminf(tout, fmaxf(t1, t2));
+    }
+    return tin - __builtin_fabsf(tin) * 1e-5f <= tout + __builtin_fabsf(tout) * 1e-5f;
+}
+
 // The ray in the sheared coordinate  w = z - (c + a (x - xc) + b (y - yc))  of a node whose centre is
 // (xc,yc) in order space: w(t) = gz + t dz.  (a,b) are stored for actual coordinates; mirroring an
 // axis into order space flips the sign of its slope.  mz grows by the slope times the xy uncertainty
@@ -1309,6 +1354,11 @@ struct hf_trace_args {
     float aux_kappa;
     int aux_antithetic;
     const uint32_t *aux_ray_id;
+    // ... samples aux_k .. aux_k + aux_n - 1 in ONE launch (hf_reparam_trace_all): sample j of ray i is written at
+    // [j * aux_stride + i] of every output row; aux_cull > 0: sqrt(2) ||to_object|| tan(theta_max) of cone_maybe_alive
+    uint32_t aux_n;
+    size_t aux_stride;
+    float aux_cull;
 };
 
 // member-wise copy out of the kernarg segment (constant address space)
@@ -1490,19 +1540,61 @@ __global__ __launch_bounds__(HF_BLOCK, (MODE == 2 ? HF_TRACE_WAVES_FUSED : HF_TR
             const size_t left = n - ub; // >= 1
             const bool valid = lane < left;
             const uint32_t lo = valid ? lane : (uint32_t) (left - 1);
-            if ((sub & 255u) == 0u) { // first batch of a fetch: nothing was requested ahead (see the end of the body)
+            if ((MODE == 2 && AUX) || (sub & 255u) == 0u) { // first batch of a fetch: nothing was requested ahead (see the end of the body; AUX never requests ahead)
                 const hf_rays_dev rp = load_rays(ka);
                 o = mk3((rp.o[0] + ub)[lo], (rp.o[1] + ub)[lo], (rp.o[2] + ub)[lo]);
                 d = mk3((rp.d[0] + ub)[lo], (rp.d[1] + ub)[lo], (rp.d[2] + ub)[lo]);
                 maxt = (rp.maxt + ub)[lo];
             }
             if (MODE == 2 && AUX) {
+                // ---- all samples of all 64 rays at once: when no auxiliary ray of the batch can enter the bound (60 % of
+                // the bench wavefront), the aux_n miss records go out without a single sample being drawn ----
+                const float ct = ka->aux_cull;
+                if (ct > 0.f) { // wave-uniform
+                    bool maybe;
+                    {
+                        const hf_dev_field f0 = load_field(&ka->f);
+                        maybe = valid && cone_maybe_alive(f0, f0.mip[1], o, d, ct);
+                    }
+                    if (__ballot(maybe) == 0ull) {
+                        {
+                            const uint32_t aux_n = ka->aux_n;
+#pragma unroll 1
+                            for (uint32_t ak = 0; ak < aux_n; ++ak) { // wave-uniform loop, the stores predicated inside
+                                asm volatile("" : "+s"(ka)); // opaque per sample: the ~30 pointer tests stay in the loop instead of being hoisted into (spilled) scalar pairs
+                                if (valid) {
+                                    const uint32_t flags = ka->flags;
+                                    const size_t ubo = ub + (size_t) ak * ka->aux_stride;
+                                    const hf_pi_dev pi = load_pi(ka);
+                                    if (pi.t) (pi.t + ubo)[lo] = __builtin_inff();
+                                    if (pi.u) (pi.u + ubo)[lo] = 0.f;
+                                    if (pi.v) (pi.v + ubo)[lo] = 0.f;
+                                    if (pi.prim) (pi.prim + ubo)[lo] = 0u;
+                                    hf_si_store_sink out = { ka, ubo, lo, flags };
+                                    const v3 z = mk3(0.f, 0.f, 0.f); // (the launcher culls only when si.wi -- minus the sample's direction -- is not asked for)
+                                    out.t(__builtin_inff()); out.p(z); out.boundary_test((flags & 0x40u) ? 1e8f : 0.f);
+                                    out.uv(0.f, 0.f); out.dp_dv(z); out.n(z); out.dp_du(z); out.sh_s(z); out.sh_t(z);
+                                }
+                            }
+                        }
+                        continue;
+                    }
+                }
+            }
+#pragma unroll 1
+            for (uint32_t ak = 0;; ++ak) { // (one trip unless AUX; the trip count is read from the kernarg segment at the end of the body)
+            if (MODE == 2 && AUX) {
+                asm volatile("" : "+s"(ka)); // opaque per sample: kernarg loads stay inside the loop instead of being hoisted (and spilled)
+                // the ray again (an L1 / L2 hit from the second sample on): nothing of it is held across the walk
+                const hf_rays_dev rp = load_rays(ka);
+                o = mk3((rp.o[0] + ub)[lo], (rp.o[1] + ub)[lo], (rp.o[2] + ub)[lo]);
+                const v3 dr = mk3((rp.d[0] + ub)[lo], (rp.d[1] + ub)[lo], (rp.d[2] + ub)[lo]);
                 hf_reparam_args sa = {};
-                sa.k = ka->aux_k; sa.seed = ka->aux_seed; sa.kappa = ka->aux_kappa; sa.antithetic = ka->aux_antithetic;
+                sa.k = ka->aux_k + ak; sa.seed = ka->aux_seed; sa.kappa = ka->aux_kappa; sa.antithetic = ka->aux_antithetic;
                 sa.ray_id = ka->aux_ray_id;
                 hf_aux_sample q;
-                aux_sample(sa, ub + lo, d, q);
-                d = frame_to_world(q, d, q.omega);
+                aux_sample(sa, ub + lo, dr, q);
+                d = frame_to_world(q, dr, q.omega);
                 maxt = __builtin_inff();
             }
             hf_hit best;
@@ -1555,7 +1647,11 @@ __global__ __launch_bounds__(HF_BLOCK, (MODE == 2 ? HF_TRACE_WAVES_FUSED : HF_TR
             // complete in order, so a wave that loads after its stores waits for the store acknowledgements
             // (HBM write latency) on top of its own load latency -- that serial chain, not bandwidth, bounded
             // the rays that only stream.
-            if (((sub + 64u) & 255u) != 0u && sub + 64 < grab && ub + 64 < n) { // (the next fetch decides about its own rays)
+            const bool more = (MODE == 2 && AUX) && ak + 1u < ka->aux_n; // further samples of this batch (AUX re-reads its rays: no request ahead)
+            const size_t ubo = (MODE == 2 && AUX) ? ub + (size_t) ak * ka->aux_stride : ub; // where this sample's records go
+            if (MODE == 2 && AUX) {
+                o = mk3(0.f, 0.f, 0.f); d = o; maxt = 0.f;
+            } else if (((sub + 64u) & 255u) != 0u && sub + 64 < grab && ub + 64 < n) { // (the next fetch decides about its own rays)
                 const size_t ub2 = ub + 64, left2 = n - ub2;
                 const uint32_t lo2 = lane < left2 ? lane : (uint32_t) (left2 - 1);
                 const hf_rays_dev rp = load_rays(ka);
@@ -1565,19 +1661,19 @@ __global__ __launch_bounds__(HF_BLOCK, (MODE == 2 ? HF_TRACE_WAVES_FUSED : HF_TR
             } else { // (defined on this path too, or the old values stay live across the walk)
                 o = mk3(0.f, 0.f, 0.f); d = o; maxt = 0.f;
             }
-            if (!valid) continue;
+            if (valid) { // (no per-lane exit from the sample loop: its control flow stays wave-uniform)
             if (MODE == 1) {
                 uint8_t *hit_out = ka->hit_out;
                 (hit_out + ub)[lo] = best.hit ? 1 : 0;
             } else {
                 const hf_pi_dev pi = load_pi(ka);
-                if (pi.t) (pi.t + ub)[lo] = best.hit ? best.t : __builtin_inff();
-                if (pi.u) (pi.u + ub)[lo] = best.hit ? best.u : 0.f;
-                if (pi.v) (pi.v + ub)[lo] = best.hit ? best.v : 0.f;
-                if (pi.prim) (pi.prim + ub)[lo] = best.hit ? best.prim : 0u;
+                if (pi.t) (pi.t + ubo)[lo] = best.hit ? best.t : __builtin_inff();
+                if (pi.u) (pi.u + ubo)[lo] = best.hit ? best.u : 0.f;
+                if (pi.v) (pi.v + ubo)[lo] = best.hit ? best.v : 0.f;
+                if (pi.prim) (pi.prim + ubo)[lo] = best.hit ? best.prim : 0u;
                 if (MODE == 2) {
                     const uint32_t flags = ka->flags;
-                    hf_si_store_sink out = { ka, ub, lo, flags };
+                    hf_si_store_sink out = { ka, ubo, lo, flags };
                     if (best.hit) {
                         // the origin is only needed by a hit: read again (an L2 hit) rather than held across the walk
                         const hf_rays_dev rp = load_rays(ka);
@@ -1593,6 +1689,9 @@ __global__ __launch_bounds__(HF_BLOCK, (MODE == 2 ? HF_TRACE_WAVES_FUSED : HF_TR
                     }
                 }
             }
+            } // valid
+            if (!more) break;
+            } // samples of the batch
         }
     }
 }
@@ -1692,9 +1791,27 @@ void hf_launch_trace(int mode, const hf_dev_field &f, size_t n, const hf_rays_t 
     }
     a.n_grabs = waves;
     a.aux_on = 0u; a.aux_k = 0u; a.aux_seed = 0u; a.aux_kappa = 1.f; a.aux_antithetic = 0; a.aux_ray_id = nullptr;
+    a.aux_n = 1u; a.aux_stride = 0; a.aux_cull = 0.f;
     if (aux && mode == 2) {
         a.aux_on = 1u; a.aux_k = aux->k; a.aux_seed = aux->seed; a.aux_kappa = aux->kappa; a.aux_antithetic = aux->antithetic;
         a.aux_ray_id = aux->ray_id;
+        if (aux->num > 1u) { a.aux_n = aux->num; a.aux_stride = aux->stride; }
+        // cone_maybe_alive's constant: sqrt(2) ||to_object||_2 tan(theta_max), the norm bounded by sqrt(||.||_1 ||.||_inf);
+        // cos(theta_max) = 1 - 13.83 / kappa (warp.h:557-566 with the sample clamped at 1e-6: log(1e-6) = -13.8155).
+        // Not when si.wi -- minus the sample's direction -- is asked for: a culled batch draws no sample.
+        const double cmin = 1.0 - 13.83 / (double) aux->kappa - 1e-6;
+        if (cmin > 0.7 && !sd.wi[0] && !sd.wi[1] && !sd.wi[2]) {
+            double n1 = 0.0, ninf = 0.0;
+            for (int c = 0; c < 3; ++c) {
+                double col = 0.0, row = 0.0;
+                for (int rr = 0; rr < 3; ++rr) { col += fabs((double) f.to_object[4 * rr + c]); row += fabs((double) f.to_object[4 * c + rr]); }
+                n1 = col > n1 ? col : n1; ninf = row > ninf ? row : ninf;
+            }
+            a.aux_cull = (float) (1.41422 * sqrt(n1 * ninf) * sqrt(1.0 - cmin * cmin) / cmin * 1.001);
+        }
+#ifdef HF_NO_AUX_CULL
+        a.aux_cull = 0.f;
+#endif
     }
     if (mode == 0)
         hipLaunchKernelGGL(hf_trace_kernel<0>, grid, block, 0, stream, a);

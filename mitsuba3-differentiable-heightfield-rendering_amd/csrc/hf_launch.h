@@ -57,6 +57,7 @@ struct hf_reparam_args {
     const float *o[3], *d[3];
     const uint8_t *active;
     uint32_t k, seed;
+    uint32_t num; size_t stride;                      // hf_launch_trace: samples k .. k + num - 1 in one launch, sample j at [j * stride + i] (num <= 1: sample k only)
     const uint32_t *ray_id;                           // optional: the id of ray i in the sample streams (NULL: i)
     float kappa, exponent;
     int antithetic, mode;

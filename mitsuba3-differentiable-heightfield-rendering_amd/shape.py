@@ -783,6 +783,7 @@ def _coordinate_system(n):
 
 
 REPARAM_FUSED = True   # tests switch this off to compare with the per-sample kernels
+REPARAM_ONE_LAUNCH = True   # ... and this one to compare hf_reparam_trace_all with num_rays x hf_reparam_trace
 
 
 class _ReparameterizeOp(torch.autograd.Function):
@@ -832,7 +833,7 @@ class _ReparameterizeOp(torch.autograd.Function):
             grad_o = torch.zeros((3, n), dtype=torch.float32, device=dev); grad_d = torch.zeros((3, n), dtype=torch.float32, device=dev)
         # The auxiliary hits of the first loop (36 B per ray and sample: pi + si.t, si.p, si.boundary_test) are kept
         # for the second one when they fit; the reference re-traces (reparam.py:296-325), which is the fallback.
-        keep = 36 * n * num_rays <= (16 << 30)
+        keep = 36 * n * num_rays <= (64 << 30)   # (288 GB of HBM per GPU: 16 samples of a 67 M-ray wavefront are 39 GB)
         store = torch.empty((num_rays if keep else 1, 9, n), dtype=torch.float32, device=dev)
         bufs = [store[k] for k in range(store.shape[0])]
         # heights only and the hits kept: after the traces ONE kernel does the rest (hf_reparam_backward: the weights of
@@ -873,7 +874,11 @@ class _ReparameterizeOp(torch.autograd.Function):
                                        gdiv.data_ptr(), C.byref(gp_p), g_t.data_ptr(),
                                        C.byref(gvd_p) if (ray_grads and mode == 1) else None, stream))
 
-        for k in range(num_rays):           # weight normalisation (reparam.py:236-256)
+        if fused and REPARAM_ONE_LAUNCH:    # all samples in one launch (a ray is fetched once; batches whose cones miss are culled)
+            rows, si_s, pi_s = structs(bufs[0])
+            check(L.hf_reparam_trace_all(shape._h, n, C.byref(o_p), C.byref(d_p), act_p, num_rays, kappa, int(antithetic), seed,
+                                         rid_p, C.byref(pi_s), C.byref(si_s), 9 * n, stream))
+        for k in range(0 if (fused and REPARAM_ONE_LAUNCH) else num_rays):   # weight normalisation (reparam.py:236-256)
             buf = bufs[k if keep else 0]
             trace(k, buf)
             if not fused:

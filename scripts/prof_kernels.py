@@ -92,6 +92,18 @@ for nm, org in (("fwd_ymajor", (0.15, 2.6, 0.9)), ("fwd_xmajor", (2.6, 0.15, 0.9
         rr = hf_amd.workload.ortho_rays(a.film, a.film, a.spp, dev, origin=org, target=(0.0, 0.0, 0.1), scale=(1.3, 1.3, 1.0))
         rs_ = shape._rays_struct(rr[0:3], rr[3:6], rr[6])
         fn[nm] = (lambda rs_=rs_, rr=rr: _capi.check(lib.hf_ray_intersect(shape._h, R, C.byref(rs_), flags, None, C.byref(pi_s), C.byref(si_s), st)))
+if os.environ.get("HF_REPARAM_ONE_LAUNCH") == "0":   # A/B: num_rays x hf_reparam_trace instead of hf_reparam_trace_all
+    from hf_amd import shape as _shape_mod
+    _shape_mod.REPARAM_ONE_LAUNCH = False
+if "reparam16" in a.kinds:   # the reference's default for prb_reparam: 16 auxiliary rays (prb_reparam.py:237)
+    hfp = shape.heightfield.requires_grad_(True)
+    ray_o16 = hf_amd.Ray3f(rays[0:3], rays[3:6], rays[6])
+    gdir16 = torch.randn(3, R, device=dev); gdv16 = torch.randn(R, device=dev)
+    def _reparam16():
+        shape.heightfield.grad = None
+        dd, det = hf_amd.reparameterize_ray(shape, ray_o16, num_rays=16, kappa=1e5, exponent=3.0)
+        ((dd * gdir16).sum() + (det * gdv16).sum()).backward()
+    fn["reparam16"] = _reparam16
 if "reparam" in a.kinds:
     # backward of reparameterize_ray (4 auxiliary rays per primary ray: 8 fused traces + 8 weight kernels + 4 adjoints)
     hfp = shape.heightfield.requires_grad_(True)

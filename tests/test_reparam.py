@@ -167,6 +167,66 @@ def test_gpu_reparam_trace_equals_aux_rays_plus_ray_intersect(hf):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kappa,anti,wi", [(1e5, True, False), (500.0, False, False), (30.0, True, False), (1e5, False, True)])
+def test_gpu_reparam_trace_all_equals_the_single_sample_launches(hf, kappa, anti, wi):
+    """hf_reparam_trace_all (every sample of a ray in ONE launch, batches whose cones miss the bound answered without a
+    sample being drawn) is bitwise num_rays x hf_reparam_trace -- on rays of which most pass far from the field (culled
+    batches), some graze its border (the cone test says maybe, the samples decide) and the rest hit; with si.wi asked
+    for (no culling: a miss record carries minus the sample's direction) and without."""
+    import ctypes as C
+    import torch
+    from hf_amd import _capi
+    L = _capi.lib()
+    rng = np.random.default_rng(33)
+    W, H = 130, 97
+    u = np.arange(W) / (W - 1.0); v = np.arange(H)[:, None] / (H - 1.0)
+    h = (0.5 + 0.3 * np.sin(2 * np.pi * 1.5 * u) * np.cos(2 * np.pi * 1.2 * v) + 0.03 * rng.uniform(-1, 1, (H, W))).astype(np.float32)
+    shape = hf.Heightfield(heightfield=torch.from_numpy(h).cuda(), max_height=0.5)
+    K, n = 5, 64 * 700 + 13
+    # a wide orthographic bundle: coherent blocks of 64 rays, two thirds of them beside the field
+    tgt = np.repeat(rng.uniform(-3.0, 3.0, (2, n // 64 + 1)), 64, axis=1)[:, :n] + rng.uniform(-0.02, 0.02, (2, n))
+    dirn = np.array([0.35, 0.2, -0.9]); dirn /= np.linalg.norm(dirn)
+    o = (np.concatenate([tgt, np.full((1, n), 0.2)]) - 2.5 * dirn[:, None]).astype(np.float32)
+    d = np.repeat(dirn[:, None], n, 1).astype(np.float32)
+    ot, dt = torch.from_numpy(o).cuda(), torch.from_numpy(d).cuda()
+    act = torch.from_numpy((rng.uniform(size=n) < 0.9).astype(np.uint8)).cuda()
+    rid = torch.from_numpy(rng.permutation(n).astype(np.int32)).cuda()
+    p3 = lambda x: (C.c_void_p * 3)(x[0].data_ptr(), x[1].data_ptr(), x[2].data_ptr())
+
+    def out():
+        buf = torch.full((K, 12, n), float("nan"), device="cuda")   # per sample: pi (4 rows), si.t, si.p, boundary_test, wi
+        def structs(k):
+            r = [buf[k, j].data_ptr() for j in range(12)]
+            pi = _capi.hf_pi_t(); pi.t, pi.prim_uv[0], pi.prim_uv[1], pi.prim_index = r[0:4]
+            si = _capi.hf_si_t(); si.t = r[4]; si.boundary_test = r[8]
+            for c in range(3):
+                si.p[c] = r[5 + c]
+                if wi:
+                    si.wi[c] = r[9 + c]
+            return pi, si
+        return buf, structs
+
+    one, s1 = out()
+    pi, si = s1(0)
+    _capi.check(L.hf_reparam_trace_all(shape._h, n, C.byref(p3(ot)), C.byref(p3(dt)), act.data_ptr(), K, kappa, int(anti), 9,
+                                       rid.data_ptr(), C.byref(pi), C.byref(si), 12 * n, None))
+    ref, s2 = out()
+    for k in range(K):
+        pi, si = s2(k)
+        _capi.check(L.hf_reparam_trace(shape._h, n, C.byref(p3(ot)), C.byref(p3(dt)), act.data_ptr(), k, kappa, int(anti), 9,
+                                       rid.data_ptr(), C.byref(pi), C.byref(si), None))
+    torch.cuda.synchronize()
+    rows = 12 if wi else 9
+    assert torch.equal(one[:, :rows].view(torch.int32), ref[:, :rows].view(torch.int32))
+    hit = torch.isfinite(ref[:, 0])
+    assert bool(hit.any()) and not bool(hit.all())
+    if kappa >= 500.0:   # (a narrow lobe: the samples stay near their ray)
+        assert 0.05 < float(hit.float().mean()) < 0.6, float(hit.float().mean())   # most rays pass beside the field, a good part hits
+        blocks = hit[:, : (n // 64) * 64].reshape(K, -1, 64).any(2).any(0)
+        assert float(blocks.float().mean()) < 0.5      # ... and more than half of the 64-ray batches have no hit at all
+
+
+@pytest.mark.gpu
 def test_gpu_aux_rays_match_oracle(hf, oracle):
     import ctypes as C
     import torch
