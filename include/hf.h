@@ -104,7 +104,11 @@ typedef struct hf_desc {
 } hf_desc_t;
 
 /* Ray3f (include/mitsuba/core/ray.h:24-82): o, d, maxt.  time/wavelengths are
- * not used by a static shape and stay on the caller's side. */
+ * not used by a static shape and stay on the caller's side.
+ * ALIGNMENT: any float alignment works.  When every ray row and every output row of a launch is 16-byte aligned and
+ * no `active` mask is given (what a device allocator hands out), the traversal kernels answer fetches of 256 rays
+ * that miss the bound as a whole -- the part of an image beside the terrain -- through 16-byte loads and stores
+ * (DESIGN 4.1 "wide path": -4 % on the BASELINE wavefront); results do not depend on it. */
 typedef struct hf_rays {
     const float *o[3];
     const float *d[3];

@@ -10,10 +10,9 @@ import numpy as np, torch
 import hf_amd, common
 from oracle import hf_oracle as O
 
-scenes, nrays, seed0 = (int(sys.argv[k]) if len(sys.argv) > k else v for k, v in ((1, 100), (2, 60000), (3, 0)))
-O.build()
-bad_total, t0 = 0, time.time()
-for sc in range(scenes):
+def make_scene(seed0, sc, nrays):
+    """scene `sc` of fuzz run `seed0`: (heights, max_height, to_world or None, kind, rays [7, n], rng) -- also used by
+    tests/tools/fuzz_resolve.py to re-examine a reported mismatch"""
     rng = np.random.default_rng(seed0 * 100003 + sc)
     W, H = (int(np.exp(rng.uniform(np.log(2), np.log(float(os.environ.get("FUZZ_MAXDIM", "700")))))) for _ in range(2))
     kind = rng.choice(["rand", "sine", "stairs", "flat", "steep", "ridge"])
@@ -26,11 +25,6 @@ for sc in range(scenes):
         h = common.heights(kind, W, H, rng)
     mh = float(np.exp(rng.uniform(np.log(1e-3), np.log(10.0))))
     tw = common.affine(int(rng.integers(1 << 30))) if rng.uniform() < 0.5 else None
-    f_o = O.OracleField(h, max_height=mh, to_world=tw)
-    props = dict(heightfield=torch.from_numpy(h), max_height=mh)
-    if tw is not None:
-        props["to_world"] = torch.from_numpy(tw)
-    f_g = hf_amd.Heightfield(props)
     n1 = nrays // 3
     parts = [common.random_rays(n1, rng, mh), common.inside_rays(n1, rng, mh)]
     # coherent packets, some from far away, some grazing
@@ -57,12 +51,40 @@ for sc in range(scenes):
     r = common.to_world_rays(np.concatenate([pk] + parts, 1), tw)
     if tw is None:   # (an affine to_world mixes the components; keep the signed zeros exact where it is the identity)
         r[3:6, -nz:] = az[3:6]
+    return h, mh, tw, kind, r, rng
+
+
+if __name__ != "__main__":
+    scenes = 0
+else:
+    scenes, nrays, seed0 = (int(sys.argv[k]) if len(sys.argv) > k else v for k, v in ((1, 100), (2, 60000), (3, 0)))
+    O.build()
+bad_total, band_lost, t0 = 0, 0, time.time()
+for sc in range(scenes):
+    h, mh, tw, kind, r, rng = make_scene(seed0, sc, nrays)
+    H, W = h.shape
+    f_o = O.OracleField(h, max_height=mh, to_world=tw)
+    props = dict(heightfield=torch.from_numpy(h), max_height=mh)
+    if tw is not None:
+        props["to_world"] = torch.from_numpy(tw)
+    f_g = hf_amd.Heightfield(props)
     rt = torch.from_numpy(r).cuda()
     ray = hf_amd.Ray3f(rt[0:3].contiguous(), rt[3:6].contiguous(), rt[6].contiguous())
     pi = f_g.ray_intersect_preliminary(ray)
     t, uu, vv, prim = f_o.ray_intersect_preliminary(r, nthreads=16, band=bool(os.environ.get("FUZZ_BAND")))
     pg, tg = pi.prim_index.cpu().numpy().view(np.uint32), pi.t.cpu().numpy()
     bad = np.nonzero((prim != pg) | (t != tg))[0]
+    if bad.size and bad.size <= 256 and os.environ.get("FUZZ_BAND"):
+        # The band checker (+-2 cells) is too narrow where the fp32 hit test's noise exceeds a cell -- needle terrain seen
+        # from tens of units away (DESIGN 4.1 "far origins").  The arbiter there is the brute force over ALL cells:
+        # a ray on which the GPU equals it is the band's loss, not a mismatch.
+        tn, _, _, pn = f_o.ray_intersect_preliminary(np.ascontiguousarray(r[:, bad]), naive=True, nthreads=16)
+        lost = (pn == pg[bad]) & (tn == tg[bad])
+        if lost.any():
+            band_lost += int(lost.sum())
+            print(f"scene {sc} ({W}x{H} {kind} mh={mh:.3g}): the band loses {int(lost.sum())} rays to the full brute force (GPU == full); "
+                  f"origin distance {float(np.linalg.norm(r[0:3, bad[lost][0]])):.1f}", flush=True)
+        bad = bad[~lost]
     st = f_g.ray_test(ray).cpu().numpy()
     bad2 = np.nonzero(st != np.isfinite(t))[0]
     if bad.size or bad2.size:
@@ -104,5 +126,6 @@ for sc in range(scenes):
             print(f"scene {sc}: height gradient rel L2 err {err:.3g} (|g| {np.linalg.norm(gh):.3g})", flush=True)
     if sc % 20 == 0:
         print(f"scene {sc}: {W}x{H} {kind}, hit fraction {np.isfinite(t).mean():.2f}, {time.time() - t0:.0f} s", flush=True)
-print(f"{scenes} scenes x {r.shape[1]} rays: {bad_total} mismatches")
-sys.exit(1 if bad_total else 0)
+if __name__ == "__main__":
+    print(f"{scenes} scenes x {r.shape[1]} rays: {bad_total} mismatches" + (f" ({band_lost} rays on which the band lost to the full brute force and the GPU did not)" if band_lost else ""))
+    sys.exit(1 if bad_total else 0)
