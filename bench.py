@@ -335,7 +335,7 @@ def _rows_of(buf, n):
     return [buf.data_ptr() + 4 * n * k for k in range(buf.shape[0])]
 
 
-def other_launches(torch, hf_amd, _capi, lib, shape, rays, r_s, pi_s, si_s, si, R, stream, flags, iters=3):
+def other_launches(torch, hf_amd, _capi, lib, shape, rays, r_s, pi_s, si_s, si, R, stream, flags, iters=10):
     """Not part of `value`: the other entry points of the path on the same wavefront, and on the incoherent
     secondary rays of SURVEY 8d (one cosine bounce + one shadow ray per primary hit), HIP-event ms per launch."""
     dev = si.device

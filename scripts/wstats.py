@@ -44,11 +44,14 @@ if a.mode == 1:
     # (a batch exports its counters only when it took the beam sweep: prim_index then holds lane counts, not a primitive)
     # (a real hit has barycentrics in [0, 1]; the exported iteration count is at least 1)
     tk = u >= 1.0
-    print(f"traversing batches {nb}, of which through the beam sweep {float(tk.double().mean()):.3f}")
+    frac = float(tk.double().mean())
+    print(f"traversing batches {nb}, of which with at least one round of the work list {frac:.3f}; per traversing batch (the others count as zero):")
     t, u, v, pr = t[tk], u[tk], v[tk], pr[tk]
+    _m = m
+    m = lambda x: frac * _m(x)
     print(f"beam sweep: passes {m(t % 1024):.1f}, nodes box-tested per lane {m(fl(t / 1024) % 1024):.1f}, nodes with a taker {m(fl(t / 1048576)):.1f}")
     print(f"per-lane walk: iterations {m(u % 4096):.1f}, hand-offs after the hoisted visit {m(fl(u / 4096)):.1f}, visits {m(v % 4096):.1f}, cell rounds {m(fl(v / 4096)):.1f}")
-    print(f"lanes per visit {float((pr & 0xFFFF).double().mean()) / max(m(v % 4096), 1e-9):.1f}, lanes per cell round {float((pr >> 16).double().mean()) / max(m(fl(v / 4096)), 1e-9):.1f}")
+    print(f"lanes per visit {float((pr & 0xFFFF).double().mean()) / max(_m(v % 4096), 1e-9):.1f}, lanes per cell round {float((pr >> 16).double().mean()) / max(_m(fl(v / 4096)), 1e-9):.1f}")
 elif a.mode == 4:
     def split(x): return [s(x % 1024) / nb, s(fl(x / 1024) % 1024) / nb, s(fl(x / 1048576)) / nb]
     c, vv = split(t), split(u)
