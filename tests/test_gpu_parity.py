@@ -223,3 +223,74 @@ def test_wi_and_shading_frame_carry_gradients(hf, oracle):
     si2 = f_g.ray_intersect(hf.Ray3f(rt[0:3].contiguous(), rt[3:6].contiguous(), rt[6].contiguous()), hf.RayFlags.All)
     si2.sh_frame.s[2][hit].sum().backward()
     assert float(f_g.heightfield.grad.abs().max()) > 0
+
+
+def test_wide_path_equals_the_ordinary_path(hf, oracle):
+    """Fetches of 256 rays that miss the bound as a whole are answered through 16-byte loads and stores behind a
+    conservative clip (DESIGN 4.1 "wide path") -- when every row is 16-byte aligned and there is no mask.  The same
+    wavefront through rows that are NOT aligned (every buffer shifted by one float: the launcher then keeps to the
+    ordinary path) must give the same bytes in every output row, for all three launches; and both equal the oracle.
+    The rays: blocks of 256 beside the field, blocks that graze its bound within a few 1e-5 (where the conservative
+    clip has to say "maybe" and the exact one decides), blocks that hit, axis-parallel rays, rays with NaN."""
+    rng = np.random.default_rng(5)
+    h = common.heights("sine", 97, 130, rng)
+    mh = 0.4
+    shape = hf.Heightfield(heightfield=torch.from_numpy(h).cuda(), max_height=mh)
+    f = oracle.OracleField(h, max_height=mh)
+    nb = 96
+    n = nb * 256 + 77
+    kind = rng.integers(0, 4, nb + 1)
+    cx = np.where(kind == 0, rng.uniform(1.5, 4.0, nb + 1) * rng.choice([-1, 1], nb + 1),      # beside the field
+         np.where(kind == 1, (1.0 + rng.uniform(-3e-5, 3e-5, nb + 1)) * rng.choice([-1, 1], nb + 1),   # grazing its xy bound
+                  rng.uniform(-0.9, 0.9, nb + 1)))
+    c = np.repeat(np.stack([cx, rng.uniform(-0.9, 0.9, nb + 1)]), 256, axis=1)[:, :n] + rng.uniform(-1e-5, 1e-5, (2, n))
+    d = np.repeat(np.array([[1e-3], [2e-3], [-1.0]]), n, 1) + rng.normal(size=(3, n)) * np.where(np.repeat(kind, 256)[:n] == 3, 0.3, 1e-4)
+    d /= np.linalg.norm(d, axis=0)
+    o = np.concatenate([c, np.full((1, n), 2.0)]) - 0.0 * d
+    r = np.concatenate([o, d, np.full((1, n), np.inf)]).astype(np.float32)
+    r[3:5, 5 * 256:6 * 256] = 0.0; r[5, 5 * 256:6 * 256] = -1.0          # a block of axis-parallel rays
+    r[0, 9 * 256 + 3] = np.nan                                            # a NaN in a block beside the field
+    r[6, 11 * 256:12 * 256:7] = -1.0                                      # negative maxt
+    import ctypes as C
+    from hf_amd import _capi
+    lib = _capi.lib()
+
+    def run(shift):
+        """every row of every buffer starts `shift` floats into its allocation"""
+        P = n + 8
+        rays = torch.zeros((7, P), device="cuda"); rays[:, shift:shift + n] = torch.from_numpy(r).cuda()
+        pib = torch.full((4, P), 7.0, device="cuda"); sib = torch.full((29, P), 7.0, device="cuda")
+        hit = torch.full((P * 4,), 9, dtype=torch.uint8, device="cuda")
+        base = lambda b, k: b.data_ptr() + 4 * (P * k + shift)
+        rs = _capi.hf_rays_t()
+        for k in range(3):
+            rs.o[k] = base(rays, k); rs.d[k] = base(rays, 3 + k)
+        rs.maxt = base(rays, 6)
+        pi = _capi.hf_pi_t(); pi.t, pi.prim_uv[0], pi.prim_uv[1], pi.prim_index = (base(pib, k) for k in range(4))
+        si = _capi.hf_si_t()
+        rows = [base(sib, k) for k in range(29)]
+        si.t, si.boundary_test, si.uv[0], si.uv[1] = rows[0], rows[1], rows[2], rows[3]
+        for cc in range(3):
+            si.p[cc], si.n[cc], si.sh_n[cc], si.dp_du[cc] = rows[4 + cc], rows[7 + cc], rows[10 + cc], rows[13 + cc]
+            si.dp_dv[cc], si.sh_s[cc], si.sh_t[cc], si.wi[cc] = rows[16 + cc], rows[19 + cc], rows[22 + cc], rows[25 + cc]
+        flags = int(hf.RayFlags.All | hf.RayFlags.BoundaryTest)
+        _capi.check(lib.hf_ray_intersect(shape._h, n, C.byref(rs), flags, None, C.byref(pi), C.byref(si), None))
+        fused = (pib[:, shift:shift + n].clone(), sib[:28, shift:shift + n].clone())
+        pib.fill_(7.0)
+        _capi.check(lib.hf_ray_intersect_preliminary(shape._h, n, C.byref(rs), None, C.byref(pi), None))
+        prelim = pib[:, shift:shift + n].clone()
+        _capi.check(lib.hf_ray_test(shape._h, n, C.byref(rs), None, hit.data_ptr() + 4 * shift, None))
+        torch.cuda.synchronize()
+        assert bool((pib[:, :shift] == 7.0).all()) and bool((pib[:, shift + n:] == 7.0).all())   # nothing written beside the rows
+        return fused, prelim, hit[4 * shift:4 * shift + n].clone()
+
+    (pa, sa), qa, ha = run(0)     # 16-byte aligned rows: wide path
+    (pb, sb), qb, hb = run(1)     # rows shifted by one float: ordinary path
+    assert torch.equal(pa.view(torch.int32), pb.view(torch.int32)) and torch.equal(sa.view(torch.int32), sb.view(torch.int32))
+    assert torch.equal(qa.view(torch.int32), qb.view(torch.int32)) and torch.equal(ha, hb)
+    t, u, v, prim = f.ray_intersect_preliminary(r, naive=True, nthreads=16)
+    assert np.array_equal(prim, qa[3].view(torch.int32).cpu().numpy().view(np.uint32))
+    assert np.array_equal(t.view(np.uint32), qa[0].cpu().numpy().view(np.uint32))
+    assert np.array_equal(np.isfinite(t), ha.cpu().numpy() != 0)
+    hitf = np.isfinite(t).reshape(-1)[: nb * 256].reshape(nb, 256)
+    assert 0.2 < (~hitf.any(1)).mean() < 0.8      # a good part of the 256-ray fetches misses as a whole, a good part does not
