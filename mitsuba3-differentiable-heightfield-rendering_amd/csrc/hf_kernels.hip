@@ -10,22 +10,25 @@
 //   hf_adjoint_kernel                              reverse mode of a4, atomic scatter (row a5)
 //   hf_direct_kernel / hf_direct_adjoint_kernel, hf_adam_kernel     next rows
 //
-// Traversal = depth-first walk of the implicit quadtree over the cells, children in
-// front-to-back order (the grid is mirrored so the ray direction is non-negative on
-// both axes: "order space").  One visit of an inner node fetches its record -- a plane through
+// Traversal = a walk of the implicit quadtree over the cells (the grid is mirrored so the ray direction is
+// non-negative on both axes: "order space").  One visit of an inner node fetches its record -- a plane through
 // the node's corner heights and, per child, the range of (z - plane) over the child: "sheared
 // bounds", tight on slopes; the zero plane with plain min/max above level HF_SHEAR_TOP -- and keeps
 // the children the *fat* ray segment [0,t_hi] overlaps; the children of a level-1 node are
-// cells, whose two triangles are then tested.  Pending children live in 4-bit-per-level mask
-// stacks held in registers.
+// cells, whose two triangles are then tested.
 // The 64 rays of a coherent wave (primary rays: one pixel's samples) share the upper levels: the wave's rays are
 // bounded by a beam, the nodes of level HF_SUBTREE_LEVEL along the beam are enumerated front to back with the LANES
 // acting as node testers (one round trip for all boxes and records, parked in the wave's LDS), and the survivors are
-// box-tested per lane, their own record evaluated for all lanes at once and handed to the per-lane walk of the lanes
-// that have children to visit (walk_beam); an incoherent wave hands the root to every lane.  The per-lane walk runs
-// in converged rounds: lanes walk until they hold candidate cells, and the two-triangle test runs for all of them
-// together, one cell per lane per round.  The visited set is a conservative superset of the cells the ray can hit;
-// the per-triangle test and the tie rule are order independent, so the result equals the brute force's.
+// box-tested per lane and their own record evaluated for all lanes at once (walk_beam).  Everything below such a node is
+// a WAVE-WIDE WORK LIST (items_run, round 4): the children a lane is to visit become items (ray, node) on a stack in
+// LDS -- ballot-free prefix-sum compaction -- and every round the wave pops up to 64 of them, any lane taking any
+// item (the ray's constants come from the owning lane's registers by ds_bpermute), down to (ray, cell) items whose hits
+// are merged per ray with a 64-bit minimum in LDS.  An incoherent wave hands the root to every lane instead: per-lane
+// depth-first walk, children front to back, pending children as 4-bit-per-level mask stacks in registers, converged
+// rounds (lanes walk until they hold candidate cells; the two-triangle test runs for all of them together).
+// Fetches of 256 rays that miss the bound as a whole never get that far (the wide path of the kernel).  The visited
+// set is a conservative superset of the cells the ray can hit; the per-triangle test and the tie rule are order
+// independent, so the result equals the brute force's.
 #include "hf_device.h"
 #include "hf_launch.h"
 
@@ -280,29 +283,13 @@ __device__ __forceinline__ uint32_t *wcnt_base() {
 #define WLANES(k, sh) do { const uint64_t e_ = __ballot(true); if ((int) (threadIdx.x & 63u) == __builtin_ctzll(e_)) wcnt_base()[k] += (uint32_t) __builtin_popcountll(e_) << (sh); } while (0)
 __device__ __forceinline__ void wstats_reset() { if ((threadIdx.x & 63u) < 16u) wcnt_base()[threadIdx.x & 63u] = 0u; }
 // diagnostic build (scripts/wstats.py): the counters of this batch replace the hit record
-#if HF_WSTATS == 5
-// ... variant 5: at the points between two converged rounds where at most 8 lanes still walk: c[10] such points,
-// c[8] walkers, c[9] / c[11] pending level-1 / level-2 siblings they hold (work idle lanes could take)
-#define WSTATS_EXPORT(alive, best) do { if (alive) { const uint32_t *c = wcnt_base(); (best).hit = true; \
-        (best).t = (float) c[10] + 4096.f * (float) c[8]; (best).u = (float) c[9] + 4096.f * (float) c[11]; (best).v = 0.f; (best).prim = c[7]; } } while (0)
-#elif HF_WSTATS == 4
+#if HF_WSTATS == 4
 // ... variant 4: histogram of the lanes that run a visit (c[11..13]) / a cell round (c[8..10]): at most 8, 9..24, more
 #define WHIST(base) do { const uint64_t e_ = __ballot(true); if ((int) (threadIdx.x & 63u) == __builtin_ctzll(e_)) { \
         const int n_ = __builtin_popcountll(e_); wcnt_base()[(base) + (n_ <= 8 ? 0 : n_ <= 24 ? 1 : 2)]++; } } while (0)
 #define WSTATS_EXPORT(alive, best) do { if (alive) { const uint32_t *c = wcnt_base(); (best).hit = true; \
         (best).t = (float) c[8] + 1024.f * (float) c[9] + 1048576.f * (float) c[10]; \
         (best).u = (float) c[11] + 1024.f * (float) c[12] + 1048576.f * (float) c[13]; (best).v = 0.f; (best).prim = c[7]; } } while (0)
-#elif HF_WSTATS == 3
-// ... variant 3: c[8] = participants summed over the hand-offs of the batch, c[9] = those that took part in an earlier one
-#define WSTATS_EXPORT(alive, best) do { if (alive) { const uint32_t *c = wcnt_base(); (best).hit = true; \
-        (best).t = (float) c[5] + 4096.f * (float) c[8]; (best).u = (float) c[6] + 4096.f * (float) c[9]; \
-        (best).v = (float) c[4]; (best).prim = c[7]; } } while (0)
-#elif HF_WSTATS == 2
-// ... variant 2: how much of the walk runs when fewer than HF_WSTATS_THR lanes of the batch are still unfinished
-// (c[8] / c[9] / c[10] = visits / cell rounds / hand-offs of such "tail" hand-offs)
-#define WSTATS_EXPORT(alive, best) do { if (alive) { const uint32_t *c = wcnt_base(); (best).hit = true; \
-        (best).t = (float) c[5] + 4096.f * (float) c[8]; (best).u = (float) c[6] + 4096.f * (float) c[9]; \
-        (best).v = (float) c[4] + 4096.f * (float) c[10]; (best).prim = c[7]; } } while (0)
 #else
 #define WSTATS_EXPORT(alive, best) do { if (alive) { const uint32_t *c = wcnt_base(); (best).hit = true; \
         (best).t = (float) c[0] + 1024.f * (float) c[1] + 1048576.f * (float) c[2]; \
@@ -651,12 +638,6 @@ __device__ __forceinline__ void walk_init(hf_walk_t<STK> &w, uint32_t X0, uint32
     w.X = X0 >> 1; w.Y = Y0 >> 1; w.cur = 1u << ((X0 & 1u) | ((Y0 & 1u) << 1)); w.pend = 0u;
     w.stk = 0; w.L = L0 + 1; w.fin = false;
 }
-// start AT node (X0,Y0) of level L0 whose record the caller has already evaluated: cur0 = its order-space children to visit
-template <typename STK>
-__device__ __forceinline__ void walk_init_at(hf_walk_t<STK> &w, uint32_t X0, uint32_t Y0, int L0, uint32_t cur0) {
-    w.X = X0; w.Y = Y0; w.cur = cur0; w.pend = 0u; w.stk = 0; w.L = L0; w.fin = false;
-}
-
 // One round of the walk for every lane of the call: walk until parked or done, then the parked blocks, then
 // the candidate cells.  Lanes with w.fin set do nothing.  Returns whether this lane recorded a hit.
 template <bool ANY, typename Src, typename STK>
@@ -747,34 +728,6 @@ __device__ __forceinline__ bool walk_subtree(const hf_dev_field &f, const Src &s
     bool hit_any = false;
     do {
         hit_any |= walk_round<ANY>(f, src, rs, r, fx, fy, fxm, fym, thi, best, w);
-    } while (__ballot(!w.fin) != 0ull);
-    return hit_any;
-}
-
-// the same walk below a node whose own record the caller has evaluated (cur0: its order-space children to visit)
-template <bool ANY, typename Src>
-__device__ __forceinline__ bool walk_subtree_from(const hf_dev_field &f, const Src &src, const hf_ray_state &rs,
-                                                  const hf_trav &r, bool fx, bool fy, uint32_t fxm, uint32_t fym,
-                                                  uint32_t X0, uint32_t Y0, int L0, uint32_t cur0, float &thi, hf_hit &best) {
-    hf_walk_t<uint32_t> w;
-    walk_init_at(w, X0, Y0, L0, cur0);
-    bool hit_any = false;
-    do {
-        hit_any |= walk_round<ANY>(f, src, rs, r, fx, fy, fxm, fym, thi, best, w);
-#if defined(HF_WSTATS) && HF_WSTATS == 5
-        {   // between two rounds with at most 8 lanes still walking: how many level-1 siblings (pending children of the
-            // lane's level-2 ancestor) and level-2 siblings could be handed to idle lanes
-            const uint64_t wm = __ballot(!w.fin);
-            const int nw = __builtin_popcountll(wm);
-            if (nw != 0 && nw <= 8 && !w.fin) {
-                const uint32_t b1 = w.L == 1 ? (uint32_t) __builtin_popcount(w.stk & 15u) : 0u;
-                const uint32_t b2 = w.L == 1 ? (uint32_t) __builtin_popcount((w.stk >> 4) & 15u) : 0u;
-                uint32_t *c = wcnt_base();
-                atomicAdd(&c[9], b1); atomicAdd(&c[11], b2); atomicAdd(&c[8], 1u);
-                if ((threadIdx.x & 63u) == (uint32_t) __builtin_ctzll(wm)) c[10]++;
-            }
-        }
-#endif
     } while (__ballot(!w.fin) != 0ull);
     return hit_any;
 }
