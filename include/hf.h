@@ -108,7 +108,10 @@ typedef struct hf_desc {
  * ALIGNMENT: any float alignment works.  When every ray row and every output row of a launch is 16-byte aligned and
  * no `active` mask is given (what a device allocator hands out), the traversal kernels answer fetches of 256 rays
  * that miss the bound as a whole -- the part of an image beside the terrain -- through 16-byte loads and stores
- * (DESIGN 4.1 "wide path": -4 % on the BASELINE wavefront); results do not depend on it. */
+ * (DESIGN 4.1 "wide path": -4 % on the BASELINE wavefront); results do not depend on it.
+ * TEST HOOK: the environment variable HF_FORCE_GRAB=<64 .. 4096, a multiple of 64>, read at every trace launch, fixes
+ * the number of rays a wave fetches at a time (otherwise chosen from the size of the launch); 256 lets launches of any
+ * size take the wide path (tests/test_gpu_parity.py, tests/tools/fuzz_parity.py).  Results do not depend on it. */
 typedef struct hf_rays {
     const float *o[3];
     const float *d[3];

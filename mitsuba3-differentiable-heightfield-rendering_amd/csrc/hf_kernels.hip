@@ -29,6 +29,7 @@
 // Fetches of 256 rays that miss the bound as a whole never get that far (the wide path of the kernel).  The visited
 // set is a conservative superset of the cells the ray can hit; the per-triangle test and the tie rule are order
 // independent, so the result equals the brute force's.
+#include <stdlib.h>
 #include "hf_device.h"
 #include "hf_launch.h"
 
@@ -1695,6 +1696,12 @@ static hf_si_dev to_dev(const hf_si_t *s) {
                       // launch loses 1 % with 512
 #endif
 static uint32_t hf_grab_for(size_t n, int mode) {
+    // TEST HOOK (include/hf.h): HF_FORCE_GRAB=<multiple of 64> fixes the fetch size, so that small launches reach the paths
+    // that depend on it -- the wide path needs fetches of 256 rays, which the rule below gives to launches of > 27 M rays
+    if (const char *e = getenv("HF_FORCE_GRAB")) {
+        const long v = strtol(e, nullptr, 10);
+        if (v >= 64 && v <= 4096 && v % 64 == 0) return (uint32_t) v;
+    }
     const size_t resident = 256 * 4 * HF_TRACE_WAVES; // waves the launch keeps on the chip (about)
 #ifndef HF_FETCHES_PER_WAVE
 #define HF_FETCHES_PER_WAVE 24

@@ -284,8 +284,20 @@ def test_wide_path_equals_the_ordinary_path(hf, oracle):
         assert bool((pib[:, :shift] == 7.0).all()) and bool((pib[:, shift + n:] == 7.0).all())   # nothing written beside the rows
         return fused, prelim, hit[4 * shift:4 * shift + n].clone()
 
-    (pa, sa), qa, ha = run(0)     # 16-byte aligned rows: wide path
-    (pb, sb), qb, hb = run(1)     # rows shifted by one float: ordinary path
+    import os
+    old = os.environ.get("HF_FORCE_GRAB")
+    os.environ["HF_FORCE_GRAB"] = "256"   # (a launch this small fetches 64 rays at a time otherwise: no wide path)
+    try:
+        (pa, sa), qa, ha = run(0)     # 16-byte aligned rows: wide path
+        (pb, sb), qb, hb = run(1)     # rows shifted by one float: ordinary path
+    finally:
+        if old is None:
+            del os.environ["HF_FORCE_GRAB"]
+        else:
+            os.environ["HF_FORCE_GRAB"] = old
+    (pc, sc), qc, hc = run(0)         # and the launch as the library sizes it
+    assert torch.equal(pa.view(torch.int32), pc.view(torch.int32)) and torch.equal(sa.view(torch.int32), sc.view(torch.int32))
+    assert torch.equal(qa.view(torch.int32), qc.view(torch.int32)) and torch.equal(ha, hc)
     assert torch.equal(pa.view(torch.int32), pb.view(torch.int32)) and torch.equal(sa.view(torch.int32), sb.view(torch.int32))
     assert torch.equal(qa.view(torch.int32), qb.view(torch.int32)) and torch.equal(ha, hb)
     t, u, v, prim = f.ray_intersect_preliminary(r, naive=True, nthreads=16)
