@@ -404,6 +404,16 @@ def other_launches(torch, hf_amd, _capi, lib, shape, rays, r_s, pi_s, si_s, si, 
             rp()
         e1.record(); torch.cuda.synchronize()
         out["reparameterize_ray_backward(4 aux rays)"] = round(e0.elapsed_time(e1) / 2, 3)
+        # the reference's default for prb_reparam is 16 auxiliary rays per ray (prb_reparam.py:237): 39 GB of auxiliary hits
+        def rp16():
+            shape.heightfield.grad = None
+            dd_, det = hf_amd.reparameterize_ray(shape, ray, num_rays=16, kappa=1e5, exponent=3.0)
+            ((dd_ * gdir).sum() + (det * gdv).sum()).backward()
+        rp16(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); rp16(); e1.record(); torch.cuda.synchronize()
+        out["reparameterize_ray_backward(16 aux rays)"] = round(e0.elapsed_time(e1), 3)
+        torch.cuda.empty_cache()
         shape.heightfield.grad = None
         shape.heightfield.requires_grad_(was)
         del ray, gdir, gdv
