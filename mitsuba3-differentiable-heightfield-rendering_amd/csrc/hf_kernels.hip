@@ -1590,7 +1590,11 @@ __global__ __launch_bounds__(HF_BLOCK, (MODE == 2 ? HF_TRACE_WAVES_FUSED : HF_TR
                     const uint32_t lfxm = rs.fx ? ((1u << f.top) - 1u) : 0u, lfym = rs.fy ? ((1u << f.top) - 1u) : 0u;
                     (void) walk_subtree<MODE == 1>(f, src, rs, rs.r, rs.fx, rs.fy, lfxm, lfym, 0u, 0u, f.top, thi, best);
                 }
+#ifdef HF_WSTATS_ROOT // (diagnostic: the counters of batches that took the per-lane walk from the root as well)
+                WSTATS_EXPORT(alive, best);
+#else
                 if (coherent && f.top > HF_SUBTREE_LEVEL) WSTATS_EXPORT(alive, best);
+#endif
                 TSTAMP(7); // fold of the item walks' hit table (and whatever the stamps above do not cover)
             }
 #ifdef HF_TSTATS
