@@ -1404,16 +1404,44 @@ __global__ __launch_bounds__(HF_BLOCK, (MODE == 2 ? HF_TRACE_WAVES_FUSED : HF_TR
         const unsigned grab = kg->grab;
         const unsigned long long n_grabs = kg->n_grabs;
         unsigned long long g = 0;
+#ifdef HF_TSTATS
+        const long long tw0 = clock64(); // (wide-path stamps: before the grab number is asked for)
+#endif
         if (lane == 0) g = atomicAdd(counter + (size_t) xc * HF_COUNTER_STRIDE, 1ull);
         g = ((unsigned long long) (uint32_t) __builtin_amdgcn_readfirstlane((int) (g >> 32)) << 32) |
             (unsigned long long) (uint32_t) __builtin_amdgcn_readfirstlane((int) (g & 0xffffffffull));
+#ifdef HF_TSTATS
+        const long long tw1 = clock64(); // ... the grab number is there
+#endif
         const unsigned long long gg = g * HF_NUM_XCD + xc;
+#ifndef HF_TWO_FRONTS
+        // FOUR FRONTS (round 4): grab numbers map to rays along four fronts -- from the middle of the wavefront towards its
+        // end and towards its beginning, and from both ends inwards; an XCD takes its grabs from the fronts in turn.  A
+        // rendered wavefront is expensive in the middle rows of the image (the terrain) and all-miss at its top and bottom:
+        // with the two fronts from the middle that the kernel had until round 4, the waves traversed first and the launch
+        // ended in a phase in which all of them streamed miss records.  With fronts from the ends as well, half of the
+        // grabs in flight are cheap and half expensive for the whole launch: fused -4 %, closest hit -2.7 %, any hit
+        // -2.9 %; uniform launches (bounce rays) +1.6 % (four regions of the terrain in the caches instead of two).
+        const unsigned long long quarter = (n_grabs + 3ull) >> 2; // grabs per front (the last ones of two fronts may not exist)
+        if (gg >= 4ull * quarter) {
+            if (++tried == HF_NUM_XCD) break;
+            xc = (xc + 1u) & (HF_NUM_XCD - 1u);
+            continue;
+        }
+        const unsigned long long k = gg >> 2;
+        const unsigned front = (unsigned) ((gg + (gg >> 5)) & 3ull); // (a permutation of the four fronts within every four grab numbers)
+        const unsigned long long pos = front == 0u ? 2ull * quarter + k : front == 1u ? 2ull * quarter - 1ull - k :
+                                       front == 2u ? 4ull * quarter - 1ull - k : k;
+        if (pos >= n_grabs) continue; // (4 x quarter rounds n_grabs up: up to three positions beyond the wavefront)
+        const unsigned long long base = pos * grab;
+#else
         if (gg >= n_grabs) {
             if (++tried == HF_NUM_XCD) break;
             xc = (xc + 1u) & (HF_NUM_XCD - 1u);
             continue;
         }
         const unsigned long long base = ((gg & 1ull) ? (n_grabs >> 1) - 1ull - (gg >> 1) : (n_grabs >> 1) + (gg >> 1)) * grab;
+#endif
         // the ray of the batch in flight: requested one batch ahead (see below)
         v3 o = mk3(0.f, 0.f, 0.f), d = o;
         float maxt = 0.f;
@@ -1443,6 +1471,10 @@ __global__ __launch_bounds__(HF_BLOCK, (MODE == 2 ? HF_TRACE_WAVES_FUSED : HF_TR
 #pragma unroll
                         for (int j = 0; j < 4; ++j) maybe |= maybe_alive(f0, zr, mk3(ox[j], oy[j], oz[j]), mk3(dx[j], dy[j], dz[j]), mt[j]);
                     }
+#ifdef HF_TSTATS
+                    asm volatile("s_waitcnt vmcnt(0)");
+                    const long long tw2 = clock64(); // ... the rays are there and tested
+#endif
                     if (__ballot(maybe) == 0ull) {
                         // (opaque: constant register quadruples are otherwise hoisted out of the kernel's persistent loop,
                         // spilled, and re-loaded before every store)
@@ -1473,6 +1505,13 @@ __global__ __launch_bounds__(HF_BLOCK, (MODE == 2 ? HF_TRACE_WAVES_FUSED : HF_TR
                                 st4(sd.wi[0], ubw, l4, -dx); st4(sd.wi[1], ubw, l4, -dy); st4(sd.wi[2], ubw, l4, -dz);
                             }
                         }
+#ifdef HF_TSTATS
+                        if (MODE != 1 && sub == 0u) { // lane 0's four prim_uv[0] entries: cycles waiting for the grab number, for the rays + test, issuing the stores
+                            const long long tw3 = clock64();
+                            const hf_pi_dev pq = load_pi(kw);
+                            if (lane == 0u && pq.u) { (pq.u + ubw)[0] = (float) (tw1 - tw0); (pq.u + ubw)[1] = (float) (tw2 - tw1); (pq.u + ubw)[2] = (float) (tw3 - tw2); (pq.u + ubw)[3] = 1.f; }
+                        }
+#endif
                         sub += 192u; // (+ 64 by the loop: the next fetch of the grab)
                         continue;
                     }

@@ -26,3 +26,14 @@ print(f"batches {int(trav.sum())}: {tot:.0f} cycles per batch (stamped; the stam
 for k, nm in enumerate(names):
     if nm != "-":
         print(f"  {nm:45s} {float(c[:, k].mean()):8.0f}  {100 * float(c[:, k].mean()) / tot:5.1f} %")
+
+# the wide path (fetches of 256 rays that miss as a whole): lane 0 of such a fetch leaves three cycle counts in prim_uv[0] of its
+# first rays -- waiting for the grab number, for the rays (incl. the conservative clip), issuing the 30 + 4 stores
+u = (pi.prim_uv[0] if hasattr(pi, "prim_uv") else None)
+if u is not None:
+    u4 = u.reshape(-1, 256)[:, :4].double()
+    wide = u4[:, 3] == 1.0
+    if bool(wide.any()):
+        w3 = u4[wide]
+        print(f"wide fetches {int(wide.sum())} of {u4.shape[0]}: cycles waiting for the grab number {float(w3[:, 0].mean()):.0f} (median {float(w3[:, 0].median()):.0f}), "
+              f"rays + clip {float(w3[:, 1].mean()):.0f} (median {float(w3[:, 1].median()):.0f}), stores issued {float(w3[:, 2].mean()):.0f} (median {float(w3[:, 2].median()):.0f})")
