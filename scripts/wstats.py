@@ -17,9 +17,17 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--mode", type=int, default=1)
 ap.add_argument("--aux", type=float, default=0.0, help="kappa: trace auxiliary ray 0 of every ray (hf_reparam_aux_rays) instead of the ray itself")
 ap.add_argument("--bounce", action="store_true", help="the statistics of one cosine bounce per primary hit (SURVEY 8d's secondary rays; -DHF_WSTATS_ROOT builds export the per-lane root walk's counters)")
+ap.add_argument("--gen-bounce", default="", help="(internal) write the bounce rays of the workload to this file with the library as built in-tree, and exit")
 ap.add_argument("grid", type=int); ap.add_argument("film", type=int); ap.add_argument("spp", type=int)
 a = ap.parse_args()
-build.LIB_PATH = os.environ["HF_LIB"]; _capi._build.LIB_PATH = os.environ["HF_LIB"]
+if a.bounce and not a.gen_bounce:
+    # the bounce rays come from the primary hits of the PRODUCTION library (a diagnostic build's hit records are counters)
+    import subprocess, tempfile
+    rays_file = os.path.join(tempfile.gettempdir(), "wstats_bounce_rays.pt")
+    env = {k: v for k, v in os.environ.items() if k != "HF_LIB"}
+    subprocess.run([sys.executable, os.path.abspath(__file__), "--gen-bounce", rays_file, str(a.grid), str(a.film), str(a.spp)], env=env, check=True)
+if not a.gen_bounce:
+    build.LIB_PATH = os.environ["HF_LIB"]; _capi._build.LIB_PATH = os.environ["HF_LIB"]
 dev = torch.device("cuda", 0)
 shape = hf_amd.Heightfield(heightfield=hf_amd.workload.sine_heights(a.grid, a.grid, device=dev), max_height=0.5)
 rays = hf_amd.workload.ortho_rays(a.film, a.film, a.spp, dev)
@@ -30,11 +38,16 @@ if a.aux > 0:
     _capi.check(_capi.lib().hf_reparam_aux_rays(rays.shape[1], C.byref(p3(rays[0:3])), C.byref(p3(rays[3:6])), None, 0, a.aux, 0, 0, None,
                                                 C.byref(p3(ad)), mt.data_ptr(), None))
     rays = torch.cat([rays[0:3], ad, mt[None]])
-if a.bounce:
+if a.bounce and not a.gen_bounce:
+    rays = torch.load(rays_file, weights_only=True).to(dev)
+    os.remove(rays_file)
+if a.gen_bounce:
     si0 = shape.ray_intersect(hf_amd.Ray3f(rays[0:3].contiguous(), rays[3:6].contiguous(), rays[6].contiguous()), hf_amd.RayFlags.All)
     hit_idx = torch.nonzero(torch.isfinite(si0.t)).squeeze(1)
     hit_idx = hit_idx[: (hit_idx.numel() // 64) * 64]
     rays, _ = hf_amd.workload.secondary_rays(si0.p[:, hit_idx], si0.n[:, hit_idx], seed=0)
+    torch.save(rays.cpu(), a.gen_bounce)
+    sys.exit(0)
 pi = shape.ray_intersect_preliminary(hf_amd.Ray3f(rays[0:3].contiguous(), rays[3:6].contiguous(), rays[6].contiguous()))
 trav = (pi.t != float("inf")).reshape(-1, 64)
 z = torch.zeros(1, device=dev, dtype=torch.float64)

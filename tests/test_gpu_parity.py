@@ -306,3 +306,72 @@ def test_wide_path_equals_the_ordinary_path(hf, oracle):
     assert np.array_equal(np.isfinite(t), ha.cpu().numpy() != 0)
     hitf = np.isfinite(t).reshape(-1)[: nb * 256].reshape(nb, 256)
     assert 0.2 < (~hitf.any(1)).mean() < 0.8      # a good part of the 256-ray fetches misses as a whole, a good part does not
+
+
+def test_forced_fetch_sizes_give_the_same_bytes(hf, oracle):
+    """The size of a fetch (rays a wave takes from the work counter at a time; include/hf.h: HF_FORCE_GRAB) decides how
+    batches are grouped -- which batch asks for its successor's rays ahead, where the wide path may answer 256 rays at
+    once -- and must never show in the results: every launch with fetches of 128 / 192 / 256 / 512 rays forced gives the
+    bytes of the launch as the library sizes it (64 here), and those equal the oracle's brute force.  (Written for the ray
+    pool of round 4 -- incoherent batches of a fetch walked together, profiles/variants/ray_pool.diff, measured and not
+    kept -- and kept as a test of the fetch logic.)  The rays: random and inside-the-bound rays (per-lane walks from the
+    root), coherent packets between them (beam sweep), rays beside the field, NaN, negative maxt, a mask, a ragged end."""
+    import os
+    rng = np.random.default_rng(11)
+    h = common.heights("rand", 150, 131, rng)
+    mh = 0.6
+    tw = common.affine(3)
+    shape = hf.Heightfield(heightfield=torch.from_numpy(h).cuda(), max_height=mh, to_world=torch.from_numpy(tw))
+    f = oracle.OracleField(h, max_height=mh, to_world=tw)
+    parts = []
+    for b in range(40):
+        k = rng.integers(0, 4)
+        if k == 0:
+            parts.append(common.random_rays(64 * int(rng.integers(1, 6)), rng, mh))
+        elif k == 1:
+            parts.append(common.inside_rays(64 * int(rng.integers(1, 6)), rng, mh))
+        elif k == 2:   # a coherent packet: one pixel's worth of nearly equal rays from above
+            c = rng.uniform(-0.8, 0.8, (2, 1)); m = 64 * int(rng.integers(1, 3))
+            o = np.concatenate([c + rng.uniform(-1e-3, 1e-3, (2, m)), np.full((1, m), 2.0)])
+            d = np.array([[0.05], [0.02], [-1.0]]) + rng.normal(size=(3, m)) * 1e-4
+            parts.append(np.concatenate([o, d / np.linalg.norm(d, axis=0), np.full((1, m), np.inf)]))
+        else:          # rays beside the field between the others: dead items of a pool
+            m = 64
+            o = np.stack([rng.uniform(2, 3, m), rng.uniform(-1, 1, m), rng.uniform(0, 1, m)])
+            parts.append(np.concatenate([o, np.repeat(np.array([[1.0], [0.0], [0.0]]), m, 1), np.full((1, m), np.inf)]))
+    parts.append(common.inside_rays(37, rng, mh))   # ragged end
+    r = common.to_world_rays(np.concatenate(parts, 1), tw)
+    n = r.shape[1]
+    r[1, 100] = np.nan; r[6, 300:340:3] = -1.0
+    act = rng.uniform(size=n) < 0.9
+    rt = torch.from_numpy(r).cuda()
+    ray = hf.Ray3f(rt[0:3].contiguous(), rt[3:6].contiguous(), rt[6].contiguous())
+    actt = torch.from_numpy(act).cuda()
+
+    def run():
+        out = []
+        for a in (None, actt):
+            pi = shape.ray_intersect_preliminary(ray, active=a)
+            si = shape.ray_intersect(ray, hf.RayFlags.All, active=a)
+            st = shape.ray_test(ray, active=a)
+            out += [pi.t, pi.prim_index.to(torch.int64), pi.prim_uv[0], pi.prim_uv[1], si.t, si.p, si.n, si.uv, si.dp_du, st.to(torch.float32)]
+        torch.cuda.synchronize()
+        return [x.detach().clone() for x in out]
+
+    plain = run()   # fetches of 64 rays: no pool beyond the batch
+    old = os.environ.get("HF_FORCE_GRAB")
+    try:
+        for g in ("128", "192", "256", "512"):
+            os.environ["HF_FORCE_GRAB"] = g
+            for a, b in zip(plain, run()):
+                assert torch.equal(a.view(torch.int32) if a.dtype == torch.float32 else a, b.view(torch.int32) if b.dtype == torch.float32 else b), g
+    finally:
+        if old is None:
+            del os.environ["HF_FORCE_GRAB"]
+        else:
+            os.environ["HF_FORCE_GRAB"] = old
+    t, u, v, prim = f.ray_intersect_preliminary(r, naive=True, nthreads=16)
+    assert np.array_equal(prim, plain[1].cpu().numpy().astype(np.uint32))
+    assert np.array_equal(t.view(np.uint32), plain[0].cpu().numpy().view(np.uint32))
+    assert np.array_equal(np.isfinite(t), plain[9].cpu().numpy() != 0)
+    assert 0.2 < np.isfinite(t).mean() < 0.9
