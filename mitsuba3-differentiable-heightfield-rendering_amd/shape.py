@@ -816,9 +816,19 @@ class _ReparameterizeOp(torch.autograd.Function):
         act_p = None if act is None else act.data_ptr()
         stream = torch.cuda.current_stream(dev).cuda_stream
         flags = int(RayFlags.All | RayFlags.FollowShape | RayFlags.BoundaryTest)
-        aux_d = torch.empty_like(d); aux_maxt = torch.empty(n, dtype=torch.float32, device=dev)
-        Z = torch.zeros(n, dtype=torch.float32, device=dev); dZ = torch.zeros((3, n), dtype=torch.float32, device=dev)
-        g_p = torch.empty((3, n), dtype=torch.float32, device=dev); g_t = torch.empty(n, dtype=torch.float32, device=dev)
+        # The auxiliary hits of the first loop (36 B per ray and sample: pi + si.t, si.p, si.boundary_test) are kept
+        # for the second one when they fit; the reference re-traces (reparam.py:296-325), which is the fallback.
+        keep = 36 * n * num_rays <= (64 << 30)   # (288 GB of HBM per GPU: 16 samples of a 67 M-ray wavefront are 39 GB)
+        # heights only and the hits kept: after the traces ONE kernel does the rest (hf_reparam_backward: the weights of
+        # all samples, their sums, and the adjoint of every auxiliary hit); the traces then only write pi and
+        # si.boundary_test
+        fused = REPARAM_FUSED and keep and not ray_grads and num_rays <= 32
+        # (the per-sample kernels' intermediates: auxiliary rays, weight sums, upstream gradients of the auxiliary hits --
+        # none of them exists on the fused path, where 1.3 GB of zero fills for a 67 M-ray wavefront would be 0.2 ms)
+        m = 0 if fused else n
+        aux_d = torch.empty((3, m), dtype=torch.float32, device=dev); aux_maxt = torch.empty(m, dtype=torch.float32, device=dev)
+        Z = torch.zeros(m, dtype=torch.float32, device=dev); dZ = torch.zeros((3, m), dtype=torch.float32, device=dev)
+        g_p = torch.empty((3, m), dtype=torch.float32, device=dev); g_t = torch.empty(m, dtype=torch.float32, device=dev)
         grad_h = torch.zeros((shape.height, shape.width), dtype=torch.float32, device=dev)
         o_p, d_p, ad_p, dZ_p, gd_p, gp_p = _p3(o), _p3(d), _p3(aux_d), _p3(dZ), _p3(gd), _p3(g_p)
         r_s = shape._rays_struct(o, aux_d, aux_maxt)
@@ -831,15 +841,8 @@ class _ReparameterizeOp(torch.autograd.Function):
             go_adj = torch.empty((3, n), dtype=torch.float32, device=dev); gd_adj = torch.empty((3, n), dtype=torch.float32, device=dev)
             go_adj_p, gd_adj_p = _p3(go_adj), _p3(gd_adj)
             grad_o = torch.zeros((3, n), dtype=torch.float32, device=dev); grad_d = torch.zeros((3, n), dtype=torch.float32, device=dev)
-        # The auxiliary hits of the first loop (36 B per ray and sample: pi + si.t, si.p, si.boundary_test) are kept
-        # for the second one when they fit; the reference re-traces (reparam.py:296-325), which is the fallback.
-        keep = 36 * n * num_rays <= (64 << 30)   # (288 GB of HBM per GPU: 16 samples of a 67 M-ray wavefront are 39 GB)
         store = torch.empty((num_rays if keep else 1, 9, n), dtype=torch.float32, device=dev)
         bufs = [store[k] for k in range(store.shape[0])]
-        # heights only and the hits kept: after the traces ONE kernel does the rest (hf_reparam_backward: the weights of
-        # all samples, their sums, and the adjoint of every auxiliary hit); the traces then only write pi and
-        # si.boundary_test
-        fused = REPARAM_FUSED and keep and not ray_grads and num_rays <= 32
 
         def structs(buf):
             rows = _rows(buf, n)   # si.t, si.p[3], boundary_test | pi.t, u, v, prim_index
