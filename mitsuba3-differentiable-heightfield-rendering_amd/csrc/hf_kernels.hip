@@ -1273,6 +1273,12 @@ __device__ __forceinline__ void st4(float *p, size_t ub, uint32_t l4, f4 v) { if
 #endif
 // Scratch block of one trace launch (zeroed by hf_launch_trace): the per-XCD work counters.
 #define HF_SCR_BYTES 1024
+#ifndef HF_PRIO
+#define HF_PRIO 1     // s_setprio of a batch's traversal (0: off) ...
+#endif
+#ifndef HF_PRIO_OUT
+#define HF_PRIO_OUT 0 // ... and of its output phase; the wide path runs at 0
+#endif
 #ifndef HF_COH_WINDOW
 #define HF_COH_WINDOW 32.f // a wave is coherent when its entry points are within this many cells of the first live lane's
 #endif
@@ -1459,6 +1465,9 @@ __global__ __launch_bounds__(HF_BLOCK, (MODE == 2 ? HF_TRACE_WAVES_FUSED : HF_TR
                 asm volatile("" : "+s"(kw));
                 const size_t ubw = base + sub;
                 if (kw->wide != 0u && sub + 256u <= grab && ubw + 256u <= kw->n) { // wave-uniform
+#if HF_PRIO_OUT != 0
+                    __builtin_amdgcn_s_setprio(0);
+#endif
                     const uint32_t l4 = lane; // lane l: rays ubw + 4 l .. 4 l + 3
                     const hf_rays_dev rp = load_rays(kw);
                     const f4 ox = ((const f4 *) (rp.o[0] + ubw))[l4], oy = ((const f4 *) (rp.o[1] + ubw))[l4], oz = ((const f4 *) (rp.o[2] + ubw))[l4];
@@ -1617,6 +1626,11 @@ __global__ __launch_bounds__(HF_BLOCK, (MODE == 2 ? HF_TRACE_WAVES_FUSED : HF_TR
                 const bool coherent = __ballot(alive && !near) == 0ull;
                 // incoherent wave: the shared walk degenerates to handing the root to every live lane
                 TSTAMP(0); // ray set-up, clip and coherence test
+                // Instruction-issue priority (round 4): a wave that traverses issues ahead of the waves of its SIMD that store
+                // records or stream misses -- those wait for memory most of the time, the traversal is a chain of dependent
+                // loads and ~100-instruction visits.  Closest hit -2.5 %, any hit -1.3 %, fused -1 %, bounce rays -1.5 %
+                // (profiles/r04_ab/r04_prio; levels 1 / 2 / 3 and a middle level for the output phase measure the same).
+                __builtin_amdgcn_s_setprio(HF_PRIO);
                 // (one root-walk site for both the incoherent wave and a coherent wave whose beam sweep gives up)
                 float thi = alive ? rs.thi : -1.f; // dead lanes overlap nothing
                 bool root = alive;
@@ -1639,6 +1653,7 @@ __global__ __launch_bounds__(HF_BLOCK, (MODE == 2 ? HF_TRACE_WAVES_FUSED : HF_TR
 #ifdef HF_TSTATS
             TSTATS_EXPORT(am != 0ull, valid, best);
 #endif
+            __builtin_amdgcn_s_setprio(HF_PRIO_OUT);
             asm volatile("" : "+s"(ka)); // the ~30 output pointers: loaded here, not before the walk
             // Request the next batch's rays BEFORE this batch's records are stored: vector-memory operations
             // complete in order, so a wave that loads after its stores waits for the store acknowledgements
