@@ -111,7 +111,7 @@ if "reparam" in a.kinds:
     gdir = torch.randn(3, R, device=dev); gdv = torch.randn(R, device=dev)
     def _reparam():
         shape.heightfield.grad = None
-        dd, det = hf_amd.reparameterize_ray(shape, ray_o, num_rays=4, kappa=1e5, exponent=3.0)
+        dd, det = hf_amd.reparameterize_ray(shape, ray_o, num_rays=4, kappa=float(os.environ.get("HF_PROF_KAPPA", "1e5")), exponent=3.0)
         ((dd * gdir).sum() + (det * gdv).sum()).backward()
     fn["reparam"] = _reparam
 def clocks():
