@@ -797,7 +797,8 @@ class _ReparameterizeOp(torch.autograd.Function):
         ctx.save_for_backward(ray_o, ray_d)
         ctx.cfg = (int(num_rays), float(kappa), float(exponent), bool(antithetic), int(seed), active, ray_index)
         n = ray_o.shape[1]
-        return ray_d.detach().clone(), torch.ones(n, dtype=torch.float32, device=ray_o.device)
+        # (an alias of ray.d, not a copy -- 0.8 GB and 0.27 ms for the bench wavefront: the values are ray.d's, reparam.py:139-155)
+        return ray_d.detach(), torch.ones(n, dtype=torch.float32, device=ray_o.device)
 
     @staticmethod
     def backward(ctx, grad_direction, grad_divergence):

@@ -102,7 +102,7 @@ if "reparam16" in a.kinds:   # the reference's default for prb_reparam: 16 auxil
     def _reparam16():
         shape.heightfield.grad = None
         dd, det = hf_amd.reparameterize_ray(shape, ray_o16, num_rays=16, kappa=1e5, exponent=3.0)
-        ((dd * gdir16).sum() + (det * gdv16).sum()).backward()
+        torch.autograd.backward((dd, det), (gdir16, gdv16))
     fn["reparam16"] = _reparam16
 if "reparam" in a.kinds:
     # backward of reparameterize_ray (4 auxiliary rays per primary ray: 8 fused traces + 8 weight kernels + 4 adjoints)
@@ -112,7 +112,7 @@ if "reparam" in a.kinds:
     def _reparam():
         shape.heightfield.grad = None
         dd, det = hf_amd.reparameterize_ray(shape, ray_o, num_rays=4, kappa=float(os.environ.get("HF_PROF_KAPPA", "1e5")), exponent=3.0)
-        ((dd * gdir).sum() + (det * gdv).sum()).backward()
+        torch.autograd.backward((dd, det), (gdir, gdv))
     fn["reparam"] = _reparam
 def clocks():
     """current sclk / mclk of the first card as sysfs reports them (read right after the timed launches; informative only)"""
