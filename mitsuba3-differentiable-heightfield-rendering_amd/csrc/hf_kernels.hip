@@ -2241,6 +2241,13 @@ struct hf_reparam_bwd_args {
     float *grad_h;
 };
 
+#ifndef HF_RB_KEEP
+#define HF_RB_KEEP 4u // samples whose direction and weight the first loop of hf_reparam_backward_kernel keeps for the third
+#endif
+#ifndef HF_RB_ANCHOR
+#define HF_RB_ANCHOR (HF_RB_TILE * 7 / 16) // the tile starts this many texels before the first hit of the batch (rows and columns): 8 / 16 /
+                                          // 24 / 32 of 64 measured 21.4 / 20.8 / 20.5 / 20.5 ms for the backward with 4 samples (profiles/r04_ab/r04_rb)
+#endif
 #ifndef HF_RB_TILE
 #define HF_RB_TILE 64 // the auxiliary hits of a pixel spread over tens of cells: a larger tile than hf_adjoint_kernel's
 #endif
@@ -2276,10 +2283,16 @@ __global__ __launch_bounds__(HF_BLOCK, (HF_RB_TILE > 32 ? 2 : 5)) void hf_repara
         if (__ballot(hm != 0u) == 0ull) continue; // wave-uniform
         v3 o = mk3(0.f, 0.f, 0.f), d = o, gV = o;
         float gdivV = 0.f;
+        v3 kept_om[HF_RB_KEEP], kept_dw[HF_RB_KEEP];
+        float kept_w[HF_RB_KEEP];
+#pragma unroll
+        for (uint32_t c = 0; c < HF_RB_KEEP; ++c) { kept_om[c] = o; kept_dw[c] = o; kept_w[c] = 0.f; }
         if (hm != 0u) {
             o = mk3(ka->a.o[0][i], ka->a.o[1][i], ka->a.o[2][i]);
             d = mk3(ka->a.d[0][i], ka->a.d[1][i], ka->a.d[2][i]);
-            // first loop: Z = sum_k w_k, dZ = sum_k d_w_omega_k, in sample order from zero
+            // first loop: Z = sum_k w_k, dZ = sum_k d_w_omega_k, in sample order from zero.  The first HF_RB_KEEP samples'
+            // direction, weight and weight gradient are kept for the third loop (registers are free here: the tile's LDS
+            // limits the kernel to two waves per SIMD), the others are drawn again there
             float Zs = 0.f;
             v3 dZ = mk3(0.f, 0.f, 0.f);
             for (uint32_t k = 0; k < ka->a.num_rays; ++k) {
@@ -2292,6 +2305,9 @@ __global__ __launch_bounds__(HF_BLOCK, (HF_RB_TILE > 32 ? 2 : 5)) void hf_repara
                 reparam_weight(sa, q, d, B, w, dw);
                 Zs += w;
                 dZ.x += dw.x; dZ.y += dw.y; dZ.z += dw.z;
+#pragma unroll
+                for (uint32_t c = 0; c < HF_RB_KEEP; ++c)
+                    if (k == c) { kept_om[c] = q.omega; kept_w[c] = w; kept_dw[c] = dw; } // (k is wave-uniform)
             }
             // the part of reparam_grad_vdirect that is common to the samples of a ray
             const float Z = fmaxf(Zs, 1e-8f), iZ = 1.0f / Z;
@@ -2318,10 +2334,19 @@ __global__ __launch_bounds__(HF_BLOCK, (HF_RB_TILE > 32 ? 2 : 5)) void hf_repara
             if (hit) {
                 sa.k = k;
                 hf_aux_sample q;
-                aux_sample(sa, i, d, q);
                 float w;
                 v3 dw;
-                reparam_weight(sa, q, d, ka->a.si_bt[k * ka->a.stride + i], w, dw);
+                if (k < HF_RB_KEEP) { // wave-uniform: the values of the first loop (the same expressions on the same inputs)
+                    q.omega = kept_om[0]; w = kept_w[0]; dw = kept_dw[0];
+#pragma unroll
+                    for (uint32_t c = 1; c < HF_RB_KEEP; ++c)
+                        if (k == c) { q.omega = kept_om[c]; w = kept_w[c]; dw = kept_dw[c]; }
+                    q.sy = 0.f;
+                    coordinate_system(d, q.fs, q.ft);
+                } else {
+                    aux_sample(sa, i, d, q);
+                    reparam_weight(sa, q, d, ka->a.si_bt[k * ka->a.stride + i], w, dw);
+                }
                 const v3 gVd = mk3(__builtin_fmaf(w, gV.x, gdivV * dw.x), __builtin_fmaf(w, gV.y, gdivV * dw.y),
                                    __builtin_fmaf(w, gV.z, gdivV * dw.z));
                 const v3 da = frame_to_world(q, d, q.omega); // the auxiliary direction (= hf_reparam_aux_kernel's)
@@ -2351,7 +2376,7 @@ __global__ __launch_bounds__(HF_BLOCK, (HF_RB_TILE > 32 ? 2 : 5)) void hf_repara
             }
             if (!anchored) { // wave-uniform: the first sample with a hit anchors the tile
                 const int src = __builtin_ctzll(__ballot(hit));
-                ar = __shfl(vr[0], src) - HF_RB_TILE / 4; ac = __shfl(vc[0], src) - HF_RB_TILE / 4;
+                ar = __shfl(vr[0], src) - HF_RB_ANCHOR; ac = __shfl(vc[0], src) - HF_RB_ANCHOR;
                 anchored = true;
             }
             if (hit) {
