@@ -422,6 +422,10 @@ def other_launches(torch, hf_amd, _capi, lib, shape, rays, r_s, pi_s, si_s, si, 
     # secondary rays last: they overwrite pi / si of the primary wavefront
     sec = {
         "bounce_rays_ray_intersect": lambda: lib.hf_ray_intersect(shape._h, Rs, C.byref(b_s), flags, None, C.byref(pi_s), C.byref(si_s), stream),
+        # ... with the hint an integrator passes for its secondary rays (coherent = false, scene.h:117-146 -> hf_set_ray_coherence)
+        "bounce_rays_ray_intersect(coherent=false)": lambda: (lib.hf_set_ray_coherence(shape._h, 1),
+                                                              lib.hf_ray_intersect(shape._h, Rs, C.byref(b_s), flags, None, C.byref(pi_s), C.byref(si_s), stream),
+                                                              lib.hf_set_ray_coherence(shape._h, 0))[1],
         "shadow_rays_ray_test": lambda: lib.hf_ray_test(shape._h, Rs, C.byref(s_s), None, hit8.data_ptr(), stream),
     }
     for name, f in sec.items():

@@ -52,7 +52,8 @@
 extern "C" {
 #endif
 
-#define HF_VERSION 3 /* 2: hf_reparam_* take ray_id; hf_adjoint_rows, weighted lighting, hf_capture_reset; 3: hf_adam_step_scheduled */
+#define HF_VERSION 4 /* 2: hf_reparam_* take ray_id; hf_adjoint_rows, weighted lighting, hf_capture_reset; 3: hf_adam_step_scheduled;
+                        4: hf_set_ray_coherence */
 
 /* status codes */
 enum {
@@ -236,6 +237,20 @@ int hf_dims(const hf_field_t *hf, uint32_t *width, uint32_t *height);
  * away at 4096^2, by more than a cell from 50): a few rays in 10^5 then carry a hit of fp32 noise, which this library
  * reports whenever the noise stays within its margins -- in every such case resolved against the full brute force so
  * far (profiles/r03_far_origin.txt) -- and which a BVH over the same triangles may or may not report. */
+
+/* The `coherent` hint of Scene::ray_intersect / ray_test / ray_intersect_preliminary
+ * (include/mitsuba/render/scene.h:117-146, 188-207, 237-259: "a hint that can improve performance in the first step of
+ * finding the PreliminaryInteraction"; integrators pass coherent = true for camera rays, reparam.py:95 traces its
+ * auxiliary rays with coherent = false).  A property of the handle, read by every trace launch that follows:
+ *   HF_COHERENCE_AUTO        (default) every 64-ray batch decides for itself: packets take the beam sweep, the others
+ *                            the per-lane walk; auxiliary rays (hf_reparam_trace*) as _INCOHERENT when kappa < 4e6
+ *   HF_COHERENCE_INCOHERENT  = coherent false: kernels without the sweep (fewer registers, no LDS, 6-7 instead of 5
+ *                            waves per SIMD).  Bounce rays -8 %, the reparameterisation backward -7 %; camera rays +25 %.
+ *   HF_COHERENCE_COHERENT    = coherent true: as _AUTO, and auxiliary rays through the full kernel whatever kappa
+ * The results do not depend on it (bit for bit: tests/test_gpu_parity.py).  Serial per handle like everything else. */
+enum { HF_COHERENCE_AUTO = 0, HF_COHERENCE_INCOHERENT = 1, HF_COHERENCE_COHERENT = 2 };
+int hf_set_ray_coherence(hf_field_t *hf, int coherence);
+int hf_get_ray_coherence(const hf_field_t *hf);
 
 /* Replaces: Shape::ray_intersect_preliminary(const Ray3f&, Mask)
  * (include/mitsuba/render/shape.h:137-138, wrapper shape.h:621-629; called from

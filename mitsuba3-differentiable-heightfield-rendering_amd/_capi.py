@@ -47,6 +47,8 @@ SYMBOLS = {
     "hf_create": (C.c_int, [C.POINTER(hf_desc_t), C.POINTER(C.c_void_p)]),
     "hf_destroy": (C.c_int, [C.c_void_p]),
     "hf_capture_reset": (C.c_int, [C.c_void_p]),
+    "hf_set_ray_coherence": (C.c_int, [C.c_void_p, C.c_int]),
+    "hf_get_ray_coherence": (C.c_int, [C.c_void_p]),
     "hf_set_heights": (C.c_int, [C.c_void_p, _fp, C.c_void_p]),
     "hf_set_heights_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "hf_adam_step": (C.c_int, [C.c_void_p, _fp, _fp, _fp, _fp, C.c_double, C.c_double, C.c_double, C.c_double,

@@ -35,6 +35,7 @@ struct hf_field {
     bool slot_used[HF_NUM_SLOTS];
     uint32_t next_slot, next_capture_slot;
     std::mutex *slot_mutex;
+    int coherence;      // hf_set_ray_coherence: HF_COHERENCE_AUTO / _INCOHERENT (which instantiation the trace launches take)
 };
 
 static bool stream_capturing(hipStream_t s) {
@@ -236,6 +237,7 @@ extern "C" int hf_create(const hf_desc_t *desc, hf_field_t **out) {
         if (e == hipSuccess) e = hipMalloc((void **) &hf->slot_buf[k], cap);
         if (e == hipSuccess) hf->slot_cap[k] = cap;
     }
+    hf->coherence = HF_COHERENCE_AUTO;
     hf->slot_mutex = new (std::nothrow) std::mutex();
     if (e == hipSuccess && !hf->slot_mutex) e = hipErrorOutOfMemory;
     d.h = hf->d_heights;
@@ -445,7 +447,8 @@ extern "C" int hf_ray_intersect_preliminary(const hf_field_t *hf, size_t n, cons
     {
         slot_lease lease(hf, (hipStream_t) stream, hf_trace_scratch_bytes(n));
         if (!lease.buf) return fail(lease.code, "trace launch: %s", lease.why);
-        hf_launch_trace(0, hf->dev, n, rays, active, out, nullptr, nullptr, 0, lease.buf, (hipStream_t) stream);
+        hf_launch_trace(0, hf->dev, n, rays, active, out, nullptr, nullptr, 0, lease.buf, (hipStream_t) stream, nullptr,
+                        hf->coherence == HF_COHERENCE_INCOHERENT);
     }
     HF_HIP(hipGetLastError());
     return HF_OK;
@@ -459,7 +462,8 @@ extern "C" int hf_ray_test(const hf_field_t *hf, size_t n, const hf_rays_t *rays
     {
         slot_lease lease(hf, (hipStream_t) stream, hf_trace_scratch_bytes(n));
         if (!lease.buf) return fail(lease.code, "trace launch: %s", lease.why);
-        hf_launch_trace(1, hf->dev, n, rays, active, nullptr, out_hit, nullptr, 0, lease.buf, (hipStream_t) stream);
+        hf_launch_trace(1, hf->dev, n, rays, active, nullptr, out_hit, nullptr, 0, lease.buf, (hipStream_t) stream, nullptr,
+                        hf->coherence == HF_COHERENCE_INCOHERENT);
     }
     HF_HIP(hipGetLastError());
     return HF_OK;
@@ -488,7 +492,8 @@ extern "C" int hf_ray_intersect(const hf_field_t *hf, size_t n, const hf_rays_t 
     {
         slot_lease lease(hf, (hipStream_t) stream, hf_trace_scratch_bytes(n));
         if (!lease.buf) return fail(lease.code, "trace launch: %s", lease.why);
-        hf_launch_trace(2, hf->dev, n, rays, active, out_pi, nullptr, out_si, ray_flags, lease.buf, (hipStream_t) stream);
+        hf_launch_trace(2, hf->dev, n, rays, active, out_pi, nullptr, out_si, ray_flags, lease.buf, (hipStream_t) stream, nullptr,
+                        hf->coherence == HF_COHERENCE_INCOHERENT);
     }
     HF_HIP(hipGetLastError());
     return HF_OK;
@@ -716,6 +721,29 @@ extern "C" int hf_reparam_weights(int mode, size_t n, const float *const o[3], c
     return HF_OK;
 }
 
+// Which instantiation traces auxiliary rays: the lean one (every wave walks per lane) when the handle is set to
+// incoherent rays, and in the automatic mode when kappa is below HF_AUX_LEAN_KAPPA -- the reference traces its auxiliary
+// rays with coherent = false (reparam.py:95), and on the bench wavefront (camera 2.6 units from the terrain, cells of
+// 1/2048 unit) the lean kernel wins up to kappa = 1.6e6 (15.7 vs 16.5 ms), ties at 6.4e6 and loses beyond (1e8, where the
+// auxiliary rays are the primary ray: 13.9 vs 11.1 ms; profiles/r04_ab/r04_lean).
+#ifndef HF_AUX_LEAN_KAPPA
+#define HF_AUX_LEAN_KAPPA 4e6f
+#endif
+static bool aux_lean(const hf_field_t *hf, float kappa) {
+    if (hf->coherence == HF_COHERENCE_INCOHERENT) return true;
+    if (hf->coherence == HF_COHERENCE_COHERENT) return false;
+    return kappa < HF_AUX_LEAN_KAPPA;
+}
+
+extern "C" int hf_set_ray_coherence(hf_field_t *hf, int coherence) {
+    if (!hf) return fail(HF_EINVAL, "hf_set_ray_coherence: NULL handle");
+    if (coherence != HF_COHERENCE_AUTO && coherence != HF_COHERENCE_INCOHERENT && coherence != HF_COHERENCE_COHERENT)
+        return fail(HF_EINVAL, "hf_set_ray_coherence: unknown mode %d", coherence);
+    hf->coherence = coherence;
+    return HF_OK;
+}
+extern "C" int hf_get_ray_coherence(const hf_field_t *hf) { return hf ? hf->coherence : HF_COHERENCE_AUTO; }
+
 extern "C" int hf_reparam_trace(const hf_field_t *hf, size_t n, const float *const o[3], const float *const d[3],
                                 const uint8_t *active, uint32_t k, float kappa, int antithetic, uint32_t seed,
                                 const uint32_t *ray_id, const hf_pi_t *out_pi, const hf_si_t *out_si, hf_stream_t stream) {
@@ -734,7 +762,7 @@ extern "C" int hf_reparam_trace(const hf_field_t *hf, size_t n, const float *con
         slot_lease lease(hf, (hipStream_t) stream, hf_trace_scratch_bytes(n));
         if (!lease.buf) return fail(lease.code, "trace launch: %s", lease.why);
         hf_launch_trace(2, hf->dev, n, &rays, active, out_pi, nullptr, out_si,
-                        HF_RAY_ALL | HF_RAY_FOLLOWSHAPE | HF_RAY_BOUNDARYTEST, lease.buf, (hipStream_t) stream, &a);
+                        HF_RAY_ALL | HF_RAY_FOLLOWSHAPE | HF_RAY_BOUNDARYTEST, lease.buf, (hipStream_t) stream, &a, aux_lean(hf, kappa));
     }
     HF_HIP(hipGetLastError());
     return HF_OK;
@@ -761,7 +789,7 @@ extern "C" int hf_reparam_trace_all(const hf_field_t *hf, size_t n, const float 
         slot_lease lease(hf, (hipStream_t) stream, hf_trace_scratch_bytes(n));
         if (!lease.buf) return fail(lease.code, "trace launch: %s", lease.why);
         hf_launch_trace(2, hf->dev, n, &rays, active, out_pi, nullptr, out_si,
-                        HF_RAY_ALL | HF_RAY_FOLLOWSHAPE | HF_RAY_BOUNDARYTEST, lease.buf, (hipStream_t) stream, &a);
+                        HF_RAY_ALL | HF_RAY_FOLLOWSHAPE | HF_RAY_BOUNDARYTEST, lease.buf, (hipStream_t) stream, &a, aux_lean(hf, kappa));
     }
     HF_HIP(hipGetLastError());
     return HF_OK;

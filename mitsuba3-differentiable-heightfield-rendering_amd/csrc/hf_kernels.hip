@@ -1385,8 +1385,22 @@ struct hf_si_store_sink {
 // spread over all CUs whatever their position in the wavefront.
 // AUX (fused mode only): auxiliary ray a.aux_k of every ray is traced instead of the ray itself (hf_reparam_trace) -- an
 // instantiation of its own, so that the sampling code costs the ordinary fused launch nothing (inline it was +1.5 %).
-template <int MODE, bool AUX = false>
-__global__ __launch_bounds__(HF_BLOCK, (MODE == 2 ? HF_TRACE_WAVES_FUSED : HF_TRACE_WAVES)) void hf_trace_kernel(hf_trace_args a) {
+// LEAN (round 4): the instantiations for launches the caller declares INCOHERENT -- the `coherent = false` of
+// Scene::ray_intersect / ray_test / ray_intersect_preliminary (scene.h:117-146, 188-207, 237-259: "a hint that can improve
+// performance in the first step of finding the PreliminaryInteraction"; reparam.py:95 traces its auxiliary rays with it).
+// No wave tries the beam sweep, so the sweep, the item walk and their 29 KB of LDS are not in the kernel: 71 VGPRs (79 with
+// the sampling code) instead of 95, no spilled register, and 6 (7) waves per SIMD instead of 5.  The results are the same
+// (the per-lane walk is what a wave falls back to anyway); bounce rays 3.46 -> 3.18 ms, the reparameterisation backward
+// 20.4 -> 19.0 ms; a launch of coherent rays is up to 25 % slower with it (profiles/r04_ab/r04_lean).
+#ifndef HF_LEAN_WAVES
+#define HF_LEAN_WAVES 6
+#endif
+#ifndef HF_LEAN_WAVES_AUX
+#define HF_LEAN_WAVES_AUX 7
+#endif
+template <int MODE, bool AUX = false, bool LEAN = false>
+__global__ __launch_bounds__(HF_BLOCK, (LEAN ? (AUX ? HF_LEAN_WAVES_AUX : HF_LEAN_WAVES) : MODE == 2 ? HF_TRACE_WAVES_FUSED : HF_TRACE_WAVES))
+void hf_trace_kernel(hf_trace_args a) {
     const hf_dev_field &f = a.f;
     const unsigned lane = threadIdx.x & 63u;
     __shared__ hf_beam_lds s_beam[HF_BLOCK / 64]; // per wave: the beam and box + record of the pass's nodes (walk_beam)
@@ -1623,7 +1637,7 @@ __global__ __launch_bounds__(HF_BLOCK, (MODE == 2 ? HF_TRACE_WAVES_FUSED : HF_TR
                 const bool near = (rs.fx == fx0) & (rs.fy == fy0) & (__builtin_fabsf(rs.gx - gx0) <= HF_COH_WINDOW) &
                                   (__builtin_fabsf(rs.gy - gy0) <= HF_COH_WINDOW) &
                                   (__builtin_fabsf(ux * uy0 - uy * ux0) <= HF_COH_DIR * __builtin_fabsf(ux * uy0));
-                const bool coherent = __ballot(alive && !near) == 0ull;
+                const bool coherent = !LEAN && __ballot(alive && !near) == 0ull; // (LEAN: every wave walks per lane)
                 // incoherent wave: the shared walk degenerates to handing the root to every live lane
                 TSTAMP(0); // ray set-up, clip and coherence test
                 // Instruction-issue priority (round 4): a wave that traverses issues ahead of the waves of its SIMD that store
@@ -1778,7 +1792,7 @@ size_t hf_trace_scratch_bytes(size_t n) {
 
 void hf_launch_trace(int mode, const hf_dev_field &f, size_t n, const hf_rays_t *rays, const uint8_t *active,
                      const hf_pi_t *pi, uint8_t *hit, const hf_si_t *si, uint32_t flags, void *scratch,
-                     hipStream_t stream, const hf_reparam_args *aux) {
+                     hipStream_t stream, const hf_reparam_args *aux, bool lean) {
     if (n == 0) return;
     (void) hipMemsetAsync(scratch, 0, HF_SCR_BYTES, stream);
     hf_pi_dev p = { nullptr, nullptr, nullptr, nullptr };
@@ -1789,7 +1803,7 @@ void hf_launch_trace(int mode, const hf_dev_field &f, size_t n, const hf_rays_t 
     const hf_rays_dev r = to_dev(rays);
     const uint32_t grab = hf_grab_for(n, mode);
     size_t waves = (n + grab - 1) / grab, blocks = (waves + 3) / 4;
-    const size_t per_cu = mode == 2 ? HF_TRACE_WAVES_FUSED : HF_TRACE_WAVES;
+    const size_t per_cu = lean ? ((aux && mode == 2) ? HF_LEAN_WAVES_AUX : HF_LEAN_WAVES) : mode == 2 ? HF_TRACE_WAVES_FUSED : HF_TRACE_WAVES;
     if (blocks > 256 * per_cu) blocks = 256 * per_cu; // the resident set: that many workgroups per CU
     const dim3 grid((unsigned) blocks), block(HF_BLOCK);
     hf_trace_args a;
@@ -1831,7 +1845,16 @@ void hf_launch_trace(int mode, const hf_dev_field &f, size_t n, const hf_rays_t 
         a.aux_cull = 0.f;
 #endif
     }
-    if (mode == 0)
+    if (lean) {
+        if (mode == 0)
+            hipLaunchKernelGGL((hf_trace_kernel<0, false, true>), grid, block, 0, stream, a);
+        else if (mode == 1)
+            hipLaunchKernelGGL((hf_trace_kernel<1, false, true>), grid, block, 0, stream, a);
+        else if (a.aux_on)
+            hipLaunchKernelGGL((hf_trace_kernel<2, true, true>), grid, block, 0, stream, a);
+        else
+            hipLaunchKernelGGL((hf_trace_kernel<2, false, true>), grid, block, 0, stream, a);
+    } else if (mode == 0)
         hipLaunchKernelGGL(hf_trace_kernel<0>, grid, block, 0, stream, a);
     else if (mode == 1)
         hipLaunchKernelGGL(hf_trace_kernel<1>, grid, block, 0, stream, a);

@@ -14,7 +14,7 @@ struct hf_reparam_args;
 // aux (mode 2 only, may be NULL): trace auxiliary ray aux->k of every ray (k, seed, kappa, antithetic are read)
 void hf_launch_trace(int mode, const hf_dev_field &f, size_t n, const hf_rays_t *rays, const uint8_t *active,
                      const hf_pi_t *pi, uint8_t *hit, const hf_si_t *si, uint32_t flags, void *scratch,
-                     hipStream_t stream, const hf_reparam_args *aux = nullptr);
+                     hipStream_t stream, const hf_reparam_args *aux = nullptr, bool lean = false); // lean: the launch is declared incoherent (hf_set_ray_coherence)
 void hf_launch_si(const hf_dev_field &f, size_t n, const hf_rays_t *rays, const hf_pi_const_t *pi,
                   const uint8_t *active, const hf_si_t *si, uint32_t flags, hipStream_t stream);
 void hf_launch_adjoint(const hf_dev_field &f, size_t n, const hf_rays_t *rays, const hf_pi_const_t *pi,

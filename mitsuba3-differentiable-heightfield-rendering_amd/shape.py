@@ -362,8 +362,36 @@ class Heightfield:
         return p
 
     # ---- the hot path ---------------------------------------------------------------------
-    def ray_intersect_preliminary(self, ray, active=True):
-        """shape.h:137-138"""
+    # ---- the `coherent` hint of Scene::ray_intersect / ray_test / ray_intersect_preliminary (scene.h:117-146) ----------
+    COHERENCE_AUTO, COHERENCE_INCOHERENT, COHERENCE_COHERENT = 0, 1, 2
+
+    def set_ray_coherence(self, mode):
+        """``hf_set_ray_coherence``: which kernels the trace launches that follow take -- ``COHERENCE_AUTO`` (default:
+        every 64-ray batch decides for itself), ``COHERENCE_INCOHERENT`` (= ``coherent=False``: bounce rays, auxiliary
+        rays; kernels without the beam sweep at 6-7 waves per SIMD) or ``COHERENCE_COHERENT``.  Results never depend on it."""
+        check(_capi.lib().hf_set_ray_coherence(self._h, int(mode)))
+
+    def ray_coherence(self):
+        return int(_capi.lib().hf_get_ray_coherence(self._h))
+
+    class _Coherence:
+        """``with shape._coherent(flag):`` -- the hint for the launches inside (None: the handle's mode as it is)"""
+        def __init__(self, shape, flag):
+            self.shape, self.flag = shape, flag
+        def __enter__(self):
+            if self.flag is not None:
+                self.old = self.shape.ray_coherence()
+                self.shape.set_ray_coherence(Heightfield.COHERENCE_COHERENT if self.flag else Heightfield.COHERENCE_INCOHERENT)
+        def __exit__(self, *exc):
+            if self.flag is not None:
+                self.shape.set_ray_coherence(self.old)
+            return False
+
+    def _coherent(self, flag):
+        return Heightfield._Coherence(self, flag)
+
+    def ray_intersect_preliminary(self, ray, active=True, coherent=None):
+        """shape.h:137-138; ``coherent``: the hint of Scene::ray_intersect_preliminary (scene.h:237-259), None = the handle's mode"""
         self._check_ray(ray)
         n = len(ray)
         t = torch.empty(n, dtype=torch.float32, device=self.device)
@@ -372,17 +400,19 @@ class Heightfield:
         keep, ap = self._mask(active, n)
         rays = self._rays_struct(ray.o, ray.d, ray.maxt)
         pi = self._pi_struct(t, uv, prim)
-        check(_capi.lib().hf_ray_intersect_preliminary(self._h, n, C.byref(rays), ap, C.byref(pi), self._stream()))
+        with self._coherent(coherent):
+            check(_capi.lib().hf_ray_intersect_preliminary(self._h, n, C.byref(rays), ap, C.byref(pi), self._stream()))
         return PreliminaryIntersection3f(t, uv, prim, self)
 
-    def ray_test(self, ray, active=True):
-        """shape.h:153"""
+    def ray_test(self, ray, active=True, coherent=None):
+        """shape.h:153; ``coherent``: scene.h:188-207"""
         self._check_ray(ray)
         n = len(ray)
         hit = torch.empty(n, dtype=torch.uint8, device=self.device)
         keep, ap = self._mask(active, n)
         rays = self._rays_struct(ray.o, ray.d, ray.maxt)
-        check(_capi.lib().hf_ray_test(self._h, n, C.byref(rays), ap, hit.data_ptr(), self._stream()))
+        with self._coherent(coherent):
+            check(_capi.lib().hf_ray_test(self._h, n, C.byref(rays), ap, hit.data_ptr(), self._stream()))
         return hit.bool()
 
     # ---- scalar / packet forms (shape.h:220-240): host arrays in, host arrays out -------------------
@@ -493,8 +523,8 @@ class Heightfield:
                                                pi.prim_index, ray_flags, keep, diff)
         return self._package_si(ray, pi.t, pi.prim_index, diff, aux, ray_flags)
 
-    def ray_intersect(self, ray, ray_flags=RayFlags.All, active=True):
-        """shape.cpp:436-446: preliminary intersection + surface interaction, one fused kernel"""
+    def ray_intersect(self, ray, ray_flags=RayFlags.All, active=True, coherent=None):
+        """shape.cpp:436-446: preliminary intersection + surface interaction, one fused kernel; ``coherent``: scene.h:117-146"""
         self._check_ray(ray)
         ray_flags = int(ray_flags)
         n = len(ray)
@@ -507,8 +537,9 @@ class Heightfield:
         out = _fill(_fill(hf_si_t(), _DIFF_ROWS, _rows(diff, n)), _AUX_ROWS, _rows(aux, n))
         rays = self._rays_struct(ray.o, ray.d, ray.maxt)
         pis = self._pi_struct(t, uv, prim)
-        check(_capi.lib().hf_ray_intersect(self._h, n, C.byref(rays), ray_flags, ap, C.byref(pis), C.byref(out),
-                                           self._stream()))
+        with self._coherent(coherent):
+            check(_capi.lib().hf_ray_intersect(self._h, n, C.byref(rays), ray_flags, ap, C.byref(pis), C.byref(out),
+                                               self._stream()))
         if self._wants_grad(ray, ray_flags):
             diff = _SurfaceInteractionOp.apply(self, self.heightfield, ray.o, ray.d, ray.maxt, t, uv, prim,
                                                ray_flags, keep, diff)

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Run individual libhf kernels on the bench workload (for rocprofv3 / A-B timing).
 usage: python tools/prof_kernels.py [--grid 4096 --film 1024 --spp 64 --iters 5] kinds...
-kinds: fwd prelim si adj test miss mips sec_fwd sec_test (incoherent bounce / shadow rays from the primary hits)"""
+kinds: fwd prelim si adj test miss mips sec_fwd sec_test (incoherent bounce / shadow rays from the primary hits; sec_*_inc: with the
+coherent = false hint) fwd_inc prelim_inc (the primary wavefront with that hint: what a wrong hint costs)"""
 import argparse, ctypes as C, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -59,6 +60,11 @@ fn = {
     "miss": lambda: _capi.check(lib.hf_ray_intersect(shape._h, R, C.byref(m_s), flags, None, C.byref(pi_s), C.byref(si_s), st)),
     "mips": lambda: shape.parameters_changed(["heightfield"]),
 }
+def _inc(f):   # the same launch with the handle set to incoherent rays (hf_set_ray_coherence)
+    def g():
+        _capi.check(lib.hf_set_ray_coherence(shape._h, 1)); f(); _capi.check(lib.hf_set_ray_coherence(shape._h, 0))
+    return g
+fn["fwd_inc"] = _inc(fn["fwd"]); fn["prelim_inc"] = _inc(fn["prelim"]); fn["test_inc"] = _inc(fn["test"])
 fn["fwd"](); torch.cuda.synchronize()
 h = torch.isfinite(si[0]); gsi[0] = h.float(); gsi[1:4] = si[4:7] * h
 if any(k.startswith("sec") for k in a.kinds):
@@ -69,7 +75,8 @@ if any(k.startswith("sec") for k in a.kinds):
     b_s = shape._rays_struct(bounce[0:3], bounce[3:6], bounce[6]); s_s = shape._rays_struct(shadow[0:3], shadow[3:6], shadow[6])
     fn["sec_fwd"] = lambda: _capi.check(lib.hf_ray_intersect(shape._h, Rs, C.byref(b_s), flags, None, C.byref(pi_s), C.byref(si_s), st))
     fn["sec_test"] = lambda: _capi.check(lib.hf_ray_test(shape._h, Rs, C.byref(s_s), None, hit8.data_ptr(), st))
-    nrays = {"sec_fwd": Rs, "sec_test": Rs}
+    fn["sec_fwd_inc"] = _inc(fn["sec_fwd"]); fn["sec_test_inc"] = _inc(fn["sec_test"])   # coherent = false: what an integrator passes for its secondary rays
+    nrays = {"sec_fwd": Rs, "sec_test": Rs, "sec_fwd_inc": Rs, "sec_test_inc": Rs}
 else:
     nrays = {}
 if any(k.startswith("alive") for k in a.kinds):

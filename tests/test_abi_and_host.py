@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/hf.h but not exported by libhf.so"
     assert sorted(_capi.SYMBOLS) == declared, "python binding table out of sync with include/hf.h"
-    assert _capi.lib().hf_version() == 3   # HF_VERSION: 3 since hf_adam_step_scheduled (2: hf_reparam_* take ray_id)
+    assert _capi.lib().hf_version() == 4   # HF_VERSION: 4 since hf_set_ray_coherence (3: hf_adam_step_scheduled; 2: hf_reparam_* take ray_id)
 
 
 def test_rayflags_match_reference_values():

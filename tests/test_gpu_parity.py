@@ -375,3 +375,53 @@ def test_forced_fetch_sizes_give_the_same_bytes(hf, oracle):
     assert np.array_equal(t.view(np.uint32), plain[0].cpu().numpy().view(np.uint32))
     assert np.array_equal(np.isfinite(t), plain[9].cpu().numpy() != 0)
     assert 0.2 < np.isfinite(t).mean() < 0.9
+
+
+def test_coherence_hint_never_changes_a_result(hf, oracle):
+    """``coherent`` of Scene::ray_intersect / ray_test / ray_intersect_preliminary (scene.h:117-146, 188-207, 237-259) is
+    a performance hint: with ``coherent=False`` (hf_set_ray_coherence: kernels without the beam sweep, every wave walks
+    per lane) and ``coherent=True`` every launch gives the bytes of the automatic mode, on packets, incoherent rays and
+    dead rays alike, with a mask and without; the handle's mode is restored afterwards, and an unknown mode is refused."""
+    from hf_amd import _capi
+    rng = np.random.default_rng(21)
+    h = common.heights("sine", 300, 270, rng)      # (top level 9: the beam sweep is in play for the packets)
+    mh = 0.5
+    f_o, f_g = _mk(hf, oracle, h, max_height=mh)
+    parts = [common.random_rays(6400, rng, mh), common.inside_rays(6400, rng, mh)]
+    for b in range(60):   # packets: one pixel's worth of nearly equal rays each
+        c = rng.uniform(-0.9, 0.9, (2, 1))
+        o = np.concatenate([c + rng.uniform(-2e-3, 2e-3, (2, 64)), np.full((1, 64), 2.0)])
+        d = np.array([[0.3], [0.2], [-1.0]]) + rng.normal(size=(3, 64)) * 1e-4
+        parts.append(np.concatenate([o, d / np.linalg.norm(d, axis=0), np.full((1, 64), np.inf)]))
+    r = np.concatenate(parts, 1).astype(np.float32)
+    r[2, 77] = np.nan
+    n = r.shape[1]
+    ray = _ray(hf, r)
+    act = torch.from_numpy(rng.uniform(size=n) < 0.9).cuda()
+
+    def run(coherent):
+        out = []
+        for a in (True, act):
+            pi = f_g.ray_intersect_preliminary(ray, active=a, coherent=coherent)
+            si = f_g.ray_intersect(ray, hf.RayFlags.All | hf.RayFlags.BoundaryTest, active=a, coherent=coherent)
+            st = f_g.ray_test(ray, active=a, coherent=coherent)
+            out += [pi.t, pi.prim_index.to(torch.float32), pi.prim_uv, si.t, si.p, si.n, si.uv, si.dp_du, si.boundary_test, st.to(torch.float32)]
+        torch.cuda.synchronize()
+        return [x.detach().clone() for x in out]
+
+    auto = run(None)
+    assert f_g.ray_coherence() == f_g.COHERENCE_AUTO
+    for flag in (False, True):
+        for a, b in zip(auto, run(flag)):
+            assert torch.equal(a.view(torch.int32), b.view(torch.int32)), f"coherent={flag}"
+        assert f_g.ray_coherence() == f_g.COHERENCE_AUTO      # restored
+    f_g.set_ray_coherence(f_g.COHERENCE_INCOHERENT)
+    for a, b in zip(auto, run(None)):
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    assert _capi.lib().hf_set_ray_coherence(f_g._h, 7) == _capi.HF_EINVAL
+    assert f_g.ray_coherence() == f_g.COHERENCE_INCOHERENT
+    f_g.set_ray_coherence(f_g.COHERENCE_AUTO)
+    t, u, v, prim = f_o.ray_intersect_preliminary(r)
+    assert np.array_equal(t.view(np.uint32), auto[0].cpu().numpy().view(np.uint32))
+    assert np.array_equal(prim, auto[1].cpu().numpy().astype(np.uint32))
+    assert 0.3 < np.isfinite(t).mean() < 0.95
