@@ -2,7 +2,8 @@
 """Randomised parity search (tool, not a test): random grids / transforms / ray mixes, every ray's prim_index,
 t and any-hit mask compared bit for bit with the oracle.  usage: fuzz_parity.py [scenes] [rays] [seed]
 FUZZ_BAND=1: the checker is the oracle's BAND brute force (no mips, no margins shared with the walks: trace_band)
-instead of its hierarchical walk; FUZZ_MAXDIM=n: largest grid side (default 700)."""
+instead of its hierarchical walk; FUZZ_MAXDIM=n: largest grid side (default 700); FUZZ_INCOHERENT=1: every launch with the
+coherent = false hint (lean kernels)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -68,6 +69,8 @@ for sc in range(scenes):
     if tw is not None:
         props["to_world"] = torch.from_numpy(tw)
     f_g = hf_amd.Heightfield(props)
+    if os.environ.get("FUZZ_INCOHERENT"):   # the lean kernels (hf_set_ray_coherence: coherent = false) for every launch
+        f_g.set_ray_coherence(f_g.COHERENCE_INCOHERENT)
     rt = torch.from_numpy(r).cuda()
     ray = hf_amd.Ray3f(rt[0:3].contiguous(), rt[3:6].contiguous(), rt[6].contiguous())
     pi = f_g.ray_intersect_preliminary(ray)
