@@ -1434,34 +1434,41 @@ void hf_trace_kernel(hf_trace_args a) {
         const long long tw1 = clock64(); // ... the grab number is there
 #endif
         const unsigned long long gg = g * HF_NUM_XCD + xc;
-#ifndef HF_TWO_FRONTS
         // FOUR FRONTS (round 4): grab numbers map to rays along four fronts -- from the middle of the wavefront towards its
         // end and towards its beginning, and from both ends inwards; an XCD takes its grabs from the fronts in turn.  A
         // rendered wavefront is expensive in the middle rows of the image (the terrain) and all-miss at its top and bottom:
         // with the two fronts from the middle that the kernel had until round 4, the waves traversed first and the launch
         // ended in a phase in which all of them streamed miss records.  With fronts from the ends as well, half of the
         // grabs in flight are cheap and half expensive for the whole launch: fused -4 %, closest hit -2.7 %, any hit
-        // -2.9 %; uniform launches (bounce rays) +1.6 % (four regions of the terrain in the caches instead of two).
-        const unsigned long long quarter = (n_grabs + 3ull) >> 2; // grabs per front (the last ones of two fronts may not exist)
-        if (gg >= 4ull * quarter) {
-            if (++tried == HF_NUM_XCD) break;
-            xc = (xc + 1u) & (HF_NUM_XCD - 1u);
-            continue;
-        }
-        const unsigned long long k = gg >> 2;
-        const unsigned front = (unsigned) ((gg + (gg >> 5)) & 3ull); // (a permutation of the four fronts within every four grab numbers)
-        const unsigned long long pos = front == 0u ? 2ull * quarter + k : front == 1u ? 2ull * quarter - 1ull - k :
-                                       front == 2u ? 4ull * quarter - 1ull - k : k;
-        if (pos >= n_grabs) continue; // (4 x quarter rounds n_grabs up: up to three positions beyond the wavefront)
-        const unsigned long long base = pos * grab;
+        // -2.9 %; uniform launches (bounce rays) +1.6 % (four regions of the terrain in the caches instead of two) -- so the
+        // LEAN instantiations, whose launches are uniform by declaration, keep the two fronts from the middle.
+#ifdef HF_TWO_FRONTS
+        const bool two_fronts = true;
 #else
-        if (gg >= n_grabs) {
-            if (++tried == HF_NUM_XCD) break;
-            xc = (xc + 1u) & (HF_NUM_XCD - 1u);
-            continue;
-        }
-        const unsigned long long base = ((gg & 1ull) ? (n_grabs >> 1) - 1ull - (gg >> 1) : (n_grabs >> 1) + (gg >> 1)) * grab;
+        const bool two_fronts = LEAN && !AUX; // (the auxiliary rays of a rendered wavefront are as uneven as the wavefront itself)
 #endif
+        unsigned long long base;
+        if (!two_fronts) {
+            const unsigned long long quarter = (n_grabs + 3ull) >> 2; // grabs per front (the last ones of two fronts may not exist)
+            if (gg >= 4ull * quarter) {
+                if (++tried == HF_NUM_XCD) break;
+                xc = (xc + 1u) & (HF_NUM_XCD - 1u);
+                continue;
+            }
+            const unsigned long long k = gg >> 2;
+            const unsigned front = (unsigned) ((gg + (gg >> 5)) & 3ull); // (a permutation of the four fronts within every four grab numbers)
+            const unsigned long long pos = front == 0u ? 2ull * quarter + k : front == 1u ? 2ull * quarter - 1ull - k :
+                                           front == 2u ? 4ull * quarter - 1ull - k : k;
+            if (pos >= n_grabs) continue; // (4 x quarter rounds n_grabs up: up to three positions beyond the wavefront)
+            base = pos * grab;
+        } else {
+            if (gg >= n_grabs) {
+                if (++tried == HF_NUM_XCD) break;
+                xc = (xc + 1u) & (HF_NUM_XCD - 1u);
+                continue;
+            }
+            base = ((gg & 1ull) ? (n_grabs >> 1) - 1ull - (gg >> 1) : (n_grabs >> 1) + (gg >> 1)) * grab;
+        }
         // the ray of the batch in flight: requested one batch ahead (see below)
         v3 o = mk3(0.f, 0.f, 0.f), d = o;
         float maxt = 0.f;
