@@ -39,8 +39,8 @@ HBM_COPY_GBS = 6290.0       # same guide: measured float4 copy (79 % of spec)
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--grid", type=int, default=4096, help="heightfield resolution N (N x N)")
     ap.add_argument("--film", type=int, default=1024)
     ap.add_argument("--spp", type=int, default=64)
