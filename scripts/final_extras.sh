@@ -8,7 +8,7 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd $R
-python scripts/prof_kernels.py --iters 10 fwd prelim test si adj miss mips sec_fwd sec_test fwd_ymajor fwd_xmajor fwd_steep 2>&1 | grep -v amdgpu.ids | tee $OUT/kinds.txt
+python scripts/prof_kernels.py --iters 10 fwd prelim test si adj miss mips sec_fwd sec_test fwd_ymajor fwd_xmajor fwd_steep sec_fwd_inc sec_test_inc 2>&1 | grep -v amdgpu.ids | tee $OUT/kinds.txt
 python scripts/prof_kernels.py --iters 3 reparam 2>&1 | grep -v amdgpu.ids | tee -a $OUT/kinds.txt
 python scripts/prof_kernels.py --iters 2 reparam16 2>&1 | grep -v amdgpu.ids | tee -a $OUT/kinds.txt
 python scripts/prof_kernels.py --iters 10 --grid 2048 --film 512 --spp 16 fwd prelim 2>&1 | grep -v amdgpu.ids | sed 's/^/configs2-size /' | tee -a $OUT/kinds.txt
